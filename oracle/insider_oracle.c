@@ -1,0 +1,672 @@
+/*
+ * insider_oracle.c — CPU restatement of the INSIDER factorisation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker for the HIP path: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build,
+ * load or call it.  The product (insider_amd/, libinsider_hip.so) never does.
+ *
+ * PARITY UNPINNED.  The reference (kai0511/insider) ships no golden vectors,
+ * known-answer tests or fixtures for this path (its tests/Rcpp_test.R is
+ * empty), and it cannot be built in this image (needs R + Rcpp +
+ * RcppArmadillo + a system BLAS/LAPACK, none present), so this restatement is
+ * pinned only by what tests/test_oracle_*.py derive from the mathematics:
+ * KKT certificates, closed-form ridge, a hand-computed K=1 case, scikit-learn's
+ * ElasticNet as an independent solver, and a second, independent numpy
+ * restatement (oracle/numpy_oracle.py).
+ *
+ * It keeps the REFERENCE'S formulation on purpose (so that it is a fair CPU
+ * baseline and an independent check of the re-derived GPU algebra):
+ *   - materialised n x p residual / predictions          src/optimize.cpp:320-378
+ *   - residual += / -= Z_i A_i C per covariate           src/optimize.cpp:338,354
+ *   - row update recomputed per covariate, complement
+ *     Gram  gram - C[:,zero] C[:,zero]'                  src/optimize.cpp:150-176
+ *   - column update with the K x K x n outer-product
+ *     cube and per-gene slice sums                       src/optimize.cpp:203-230
+ *   - residual-form coordinate descent with strong-rule
+ *     screening and KKT re-admission                     src/coordinate_descent.cpp:56-127
+ *   - loss / RMSE / decay schedule every 10th iteration  src/optimize.cpp:381-408,
+ *                                                        src/utils.cpp:46-102
+ * Third-party arithmetic the reference takes from Armadillo (RcppArmadillo,
+ * unpinned in DESCRIPTION:10-11) is restated from its documented behaviour:
+ * solve(..., likely_sympd) = Cholesky first, general LU otherwise; unique() =
+ * sorted ascending; randperm() = uniformly random order (replaced by the
+ * deterministic order of include/insider_perm.h, see there).
+ *
+ * All matrices are column-major (Armadillo / R layout).  Masks are uint8
+ * (the reference passes them as fp64 matrices, src/optimize.cpp:256).
+ * Level ids are 1-based int32, n x c column-major, exactly 1..L_i.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/insider_perm.h"
+
+#define ORACLE_OK 0
+#define ORACLE_ERR_ARG 1
+#define ORACLE_ERR_SOLVE 2
+#define ORACLE_ERR_ALLOC 3
+
+/* ------------------------------------------------------------------------- */
+/* small dense helpers                                                        */
+/* ------------------------------------------------------------------------- */
+
+/* solve(A, b, solve_opts::likely_sympd): Cholesky, falling back to LU with
+ * partial pivoting (src/optimize.cpp:175,190,226,240).  A is K x K column-major
+ * and is destroyed; b is overwritten with the solution (nrhs columns).       */
+static int solve_likely_sympd(double *A, double *b, int K, int nrhs)
+{
+    double *L = (double *)malloc(sizeof(double) * (size_t)K * K);
+    if (!L) return ORACLE_ERR_ALLOC;
+    memcpy(L, A, sizeof(double) * (size_t)K * K);
+    int ok = 1;
+    for (int j = 0; j < K && ok; j++) {
+        double d = L[j + (size_t)j * K];
+        for (int k = 0; k < j; k++) d -= L[j + (size_t)k * K] * L[j + (size_t)k * K];
+        if (!(d > 0.0)) { ok = 0; break; }
+        d = sqrt(d);
+        L[j + (size_t)j * K] = d;
+        for (int i = j + 1; i < K; i++) {
+            double s = L[i + (size_t)j * K];
+            for (int k = 0; k < j; k++) s -= L[i + (size_t)k * K] * L[j + (size_t)k * K];
+            L[i + (size_t)j * K] = s / d;
+        }
+    }
+    if (ok) {
+        for (int r = 0; r < nrhs; r++) {
+            double *x = b + (size_t)r * K;
+            for (int i = 0; i < K; i++) {
+                double s = x[i];
+                for (int k = 0; k < i; k++) s -= L[i + (size_t)k * K] * x[k];
+                x[i] = s / L[i + (size_t)i * K];
+            }
+            for (int i = K - 1; i >= 0; i--) {
+                double s = x[i];
+                for (int k = i + 1; k < K; k++) s -= L[k + (size_t)i * K] * x[k];
+                x[i] = s / L[i + (size_t)i * K];
+            }
+        }
+        free(L);
+        return ORACLE_OK;
+    }
+    free(L);
+    /* general fallback: LU with partial pivoting on A */
+    int *piv = (int *)malloc(sizeof(int) * (size_t)K);
+    if (!piv) return ORACLE_ERR_ALLOC;
+    for (int j = 0; j < K; j++) {
+        int p = j;
+        double best = fabs(A[j + (size_t)j * K]);
+        for (int i = j + 1; i < K; i++)
+            if (fabs(A[i + (size_t)j * K]) > best) { best = fabs(A[i + (size_t)j * K]); p = i; }
+        piv[j] = p;
+        if (best == 0.0) { free(piv); return ORACLE_ERR_SOLVE; }
+        if (p != j)
+            for (int k = 0; k < K; k++) {
+                double t = A[j + (size_t)k * K]; A[j + (size_t)k * K] = A[p + (size_t)k * K]; A[p + (size_t)k * K] = t;
+            }
+        for (int i = j + 1; i < K; i++) {
+            double f = A[i + (size_t)j * K] / A[j + (size_t)j * K];
+            A[i + (size_t)j * K] = f;
+            for (int k = j + 1; k < K; k++) A[i + (size_t)k * K] -= f * A[j + (size_t)k * K];
+        }
+    }
+    for (int r = 0; r < nrhs; r++) {
+        double *x = b + (size_t)r * K;
+        for (int j = 0; j < K; j++)
+            if (piv[j] != j) { double t = x[j]; x[j] = x[piv[j]]; x[piv[j]] = t; }
+        for (int i = 0; i < K; i++)
+            for (int k = 0; k < i; k++) x[i] -= A[i + (size_t)k * K] * x[k];
+        for (int i = K - 1; i >= 0; i--) {
+            for (int k = i + 1; k < K; k++) x[i] -= A[i + (size_t)k * K] * x[k];
+            x[i] /= A[i + (size_t)i * K];
+        }
+    }
+    free(piv);
+    return ORACLE_OK;
+}
+
+int oracle_solve_sympd(const double *A, const double *b, int K, int nrhs, double *x)
+{
+    double *Ac = (double *)malloc(sizeof(double) * (size_t)K * K);
+    if (!Ac) return ORACLE_ERR_ALLOC;
+    memcpy(Ac, A, sizeof(double) * (size_t)K * K);
+    memcpy(x, b, sizeof(double) * (size_t)K * nrhs);
+    int rc = solve_likely_sympd(Ac, x, K, nrhs);
+    free(Ac);
+    return rc;
+}
+
+/* compute_loss(vec) — src/utils.cpp:46-49 */
+static double sub_loss(const double *resid, int m, const double *beta, int K, double lambda, double alpha)
+{
+    double rs = 0.0, b2 = 0.0, b1 = 0.0;
+    for (int i = 0; i < m; i++) rs += resid[i] * resid[i];
+    for (int k = 0; k < K; k++) { b2 += beta[k] * beta[k]; b1 += fabs(beta[k]); }
+    return rs / 2 + (1 - alpha) * lambda * b2 / 2 + alpha * lambda * b1;
+}
+
+/* Sweep order over the active set: mode 0 = ascending hashed key
+ * (include/insider_perm.h), mode 1 = ascending index (cyclic).              */
+static void sweep_order(const int *inc, int ninc, uint64_t seed, uint32_t unit, uint32_t iter,
+                        uint32_t sweep, int mode, int *ord)
+{
+    for (int i = 0; i < ninc; i++) ord[i] = inc[i];
+    if (mode != 0) return;
+    uint32_t keys[64];
+    uint32_t base = insider_perm_base(seed, unit, iter, sweep);
+    for (int i = 0; i < ninc; i++) keys[i] = insider_perm_key(base, (uint32_t)inc[i]);
+    for (int i = 1; i < ninc; i++) { /* insertion sort, ninc <= 64 */
+        uint32_t kk = keys[i]; int v = ord[i]; int j = i - 1;
+        while (j >= 0 && keys[j] > kk) { keys[j + 1] = keys[j]; ord[j + 1] = ord[j]; j--; }
+        keys[j + 1] = kk; ord[j + 1] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* strong_coordinate_descent — src/coordinate_descent.cpp:56-127             */
+/* ------------------------------------------------------------------------- */
+int oracle_strong_cd(const double *X, const double *y, int m, int K, const double *wstart,
+                     double lambda, double alpha, const double *XtX, const double *Xty, double tol,
+                     uint64_t seed, uint32_t unit, uint32_t iter, int order_mode, int max_sweeps,
+                     double *beta, int *sweeps_out)
+{
+    if (K < 1 || K > 64 || m < 0) return ORACLE_ERR_ARG;
+    int active[64], inc[64], ex[64], ord[64];
+    double *resid = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));
+    if (!resid) return ORACLE_ERR_ALLOC;
+
+    /* :74-78 strong rule, suggested start */
+    double mx = 0.0;
+    for (int k = 0; k < K; k++) if (fabs(Xty[k]) > mx) mx = fabs(Xty[k]);
+    double thr = alpha * (2 * lambda - mx);
+    for (int k = 0; k < K; k++) {
+        beta[k] = wstart[k];
+        active[k] = 1;
+        if (fabs(Xty[k]) < thr) { active[k] = 0; beta[k] = 0.0; }
+    }
+    /* :79-80 */
+    for (int i = 0; i < m; i++) resid[i] = y[i];
+    for (int k = 0; k < K; k++) {
+        double b = beta[k];
+        if (b != 0.0) { const double *xk = X + (size_t)k * m; for (int i = 0; i < m; i++) resid[i] -= b * xk[i]; }
+    }
+    double iter_loss = sub_loss(resid, m, beta, K, lambda, alpha), pre_loss;
+    uint32_t sweep = 0;
+    int capped = 0;
+
+    for (;;) {
+        int ninc = 0, nex = 0;
+        for (int k = 0; k < K; k++) { if (active[k]) inc[ninc++] = k; else ex[nex++] = k; }
+        do { /* :86-114 */
+            pre_loss = iter_loss;
+            sweep_order(inc, ninc, seed, unit, iter, sweep, order_mode, ord);
+            sweep++;
+            for (int t = 0; t < ninc; t++) {
+                int k = ord[t];
+                const double *xk = X + (size_t)k * m;
+                double dot = 0.0;
+                for (int i = 0; i < m; i++) dot += resid[i] * xk[i];
+                double gkk = XtX[k + (size_t)k * K];
+                double u = dot + beta[k] * gkk;                               /* :94 */
+                double upd;
+                if (fabs(u) > lambda * alpha) {                               /* :99-104 */
+                    double sg = (u > 0) - (u < 0);
+                    upd = sg * fmax(fabs(u) - lambda * alpha, 0.0) / (gkk + lambda * (1 - alpha));
+                } else upd = 0.0;
+                if (upd != beta[k]) {                                         /* :106-109 */
+                    double d = upd - beta[k];
+                    for (int i = 0; i < m; i++) resid[i] -= d * xk[i];
+                    beta[k] = upd;
+                }
+            }
+            iter_loss = sub_loss(resid, m, beta, K, lambda, alpha);           /* :112 */
+            if ((int)sweep >= max_sweeps) { capped = 1; break; }
+        } while (fabs(pre_loss - iter_loss) > tol);                           /* :114 */
+        if (capped) break;
+        /* :117-124 KKT check on the excluded set */
+        int nviol = 0;
+        for (int e = 0; e < nex; e++) {
+            int r = ex[e];
+            double g = -Xty[r];
+            for (int t = 0; t < ninc; t++) g += XtX[r + (size_t)inc[t] * K] * beta[inc[t]];
+            if (fabs(g) > alpha * lambda) { active[r] = 1; nviol++; }
+        }
+        if (nviol == 0) break;
+    }
+    free(resid);
+    if (sweeps_out) *sweeps_out = (int)sweep;
+    return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* masked Gram / XtY of one gene, reference formulation                      */
+/* src/optimize.cpp:216-222 (cube slices summed over held-out samples)       */
+/* ------------------------------------------------------------------------- */
+void oracle_masked_gram_col(const double *xcol, const uint8_t *mcol, const double *R, int n, int K,
+                            const double *gram /*R'R*/, double *XtX, double *Xty)
+{
+    for (int a = 0; a < K * K; a++) XtX[a] = 0.0;
+    for (int a = 0; a < K; a++) Xty[a] = 0.0;
+    for (int i = 0; i < n; i++) {
+        if (mcol[i] == 0) {
+            for (int b = 0; b < K; b++) {
+                double rb = R[i + (size_t)b * n];
+                for (int a = 0; a < K; a++) XtX[a + (size_t)b * K] += R[i + (size_t)a * n] * rb;
+            }
+        } else {
+            double x = xcol[i];
+            for (int a = 0; a < K; a++) Xty[a] += R[i + (size_t)a * n] * x;
+        }
+    }
+    for (int a = 0; a < K * K; a++) XtX[a] = gram[a] - XtX[a];
+}
+
+/* masked Gram / XtY of one sample against C (src/optimize.cpp:162-171), with
+ * `vals` the row of the matrix being regressed (residual row in optimize_row). */
+void oracle_masked_gram_row(const double *vals /*stride n*/, const uint8_t *mrow /*stride n*/, int n, int p,
+                            const double *C /*K x p*/, int K, const double *gram /*C C'*/, double *XtX, double *Xty)
+{
+    for (int a = 0; a < K * K; a++) XtX[a] = 0.0;
+    for (int a = 0; a < K; a++) Xty[a] = 0.0;
+    for (int j = 0; j < p; j++) {
+        const double *cj = C + (size_t)j * K;
+        if (mrow[(size_t)j * n] == 0) {
+            for (int b = 0; b < K; b++) for (int a = 0; a < K; a++) XtX[a + (size_t)b * K] += cj[a] * cj[b];
+        } else {
+            double v = vals[(size_t)j * n];
+            for (int a = 0; a < K; a++) Xty[a] += cj[a] * v;
+        }
+    }
+    for (int a = 0; a < K * K; a++) XtX[a] = gram[a] - XtX[a];
+}
+
+/* ------------------------------------------------------------------------- */
+/* optimize_row — src/optimize.cpp:139-198                                   */
+/* ------------------------------------------------------------------------- */
+int oracle_optimize_row(const double *residual, const uint8_t *M, double *A /*L x K*/, const double *C,
+                        const int32_t *levels /*n, 1-based*/, const double *gram, double lambda, int tuning,
+                        int n, int p, int K, int L, int n_threads)
+{
+    if (tuning != 0 && tuning != 1) return ORACLE_ERR_ARG;
+    int rc_all = ORACLE_OK;
+    double *Xtys = NULL;
+    if (tuning == 0) { /* :180  Xtys = C * residual'  (K x n) */
+        Xtys = (double *)calloc((size_t)K * n, sizeof(double));
+        if (!Xtys) return ORACLE_ERR_ALLOC;
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+        for (int r = 0; r < n; r++)
+            for (int j = 0; j < p; j++) {
+                double v = residual[r + (size_t)j * n];
+                const double *cj = C + (size_t)j * K;
+                for (int a = 0; a < K; a++) Xtys[a + (size_t)r * K] += cj[a] * v;
+            }
+    }
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+    for (int l = 1; l <= L; l++) {
+        double *XtX = (double *)calloc((size_t)K * K, sizeof(double));
+        double *Xty = (double *)calloc((size_t)K, sizeof(double));
+        double *tx = (double *)malloc(sizeof(double) * (size_t)K * K);
+        double *ty = (double *)malloc(sizeof(double) * (size_t)K);
+        int members = 0;
+        for (int r = 0; r < n; r++) {
+            if (levels[r] != l) continue;
+            members++;
+            if (tuning == 1) { /* :161-172 */
+                oracle_masked_gram_row(residual + r, M + r, n, p, C, K, gram, tx, ty);
+                for (int a = 0; a < K * K; a++) XtX[a] += tx[a];
+                for (int a = 0; a < K; a++) Xty[a] += ty[a];
+            } else {           /* :186-188 */
+                for (int a = 0; a < K; a++) Xty[a] += Xtys[a + (size_t)r * K];
+            }
+        }
+        if (tuning == 0) for (int a = 0; a < K * K; a++) XtX[a] = members * gram[a];
+        /* a level id in 1..L with no member sample is never visited by the
+         * reference (unique() only returns present values, :147): leave its row. */
+        if (members > 0) {
+            for (int a = 0; a < K; a++) XtX[a + (size_t)a * K] += lambda;           /* :174,187 */
+            int rc = solve_likely_sympd(XtX, Xty, K, 1);                            /* :175,190 */
+            if (rc != ORACLE_OK) {
+#pragma omp critical
+                rc_all = rc;
+            } else
+                for (int a = 0; a < K; a++) A[(l - 1) + (size_t)a * L] = Xty[a];
+        }
+        free(XtX); free(Xty); free(tx); free(ty);
+    }
+    free(Xtys);
+    return rc_all;
+}
+
+/* ------------------------------------------------------------------------- */
+/* optimize_col — src/optimize.cpp:200-253                                   */
+/* ------------------------------------------------------------------------- */
+int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x K*/, double *C /*K x p*/,
+                        double lambda, double alpha, int tuning, double tol, int n, int p, int K,
+                        uint64_t seed, uint32_t iter, int order_mode, int max_sweeps, int n_threads,
+                        int64_t gene_offset, int64_t *total_sweeps)
+{
+    if (tuning != 0 && tuning != 1) return ORACLE_ERR_ARG;
+    int rc_all = ORACLE_OK;
+    long long sweeps_sum = 0;
+    double *gram = (double *)calloc((size_t)K * K, sizeof(double));          /* :205,234 */
+    if (!gram) return ORACLE_ERR_ALLOC;
+    for (int b = 0; b < K; b++)
+        for (int a = 0; a < K; a++) {
+            double s = 0.0;
+            for (int i = 0; i < n; i++) s += R[i + (size_t)a * n] * R[i + (size_t)b * n];
+            gram[a + (size_t)b * K] = s;
+        }
+    if (tuning == 1) {
+        /* :207-210 the K x K x n cube of outer products */
+        double *cube = (double *)malloc(sizeof(double) * (size_t)K * K * n);
+        if (!cube) { free(gram); return ORACLE_ERR_ALLOC; }
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+        for (int i = 0; i < n; i++)
+            for (int b = 0; b < K; b++)
+                for (int a = 0; a < K; a++)
+                    cube[(size_t)i * K * K + a + (size_t)b * K] = R[i + (size_t)a * n] * R[i + (size_t)b * n];
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 100) reduction(+ : sweeps_sum)
+        for (int j = 0; j < p; j++) {
+            const double *xcol = X + (size_t)j * n;
+            const uint8_t *mcol = M + (size_t)j * n;
+            int m = 0;
+            for (int i = 0; i < n; i++) m += (mcol[i] != 0);
+            double *feat = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1) * K);  /* :217 */
+            double *outc = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1));      /* :220-221 */
+            double *XtX = (double *)calloc((size_t)K * K, sizeof(double));
+            double *Xty = (double *)calloc((size_t)K, sizeof(double));
+            double *beta = (double *)malloc(sizeof(double) * (size_t)K);
+            int s = 0;
+            for (int i = 0; i < n; i++) {
+                if (mcol[i] != 0) {
+                    for (int a = 0; a < K; a++) feat[s + (size_t)a * m] = R[i + (size_t)a * n];
+                    outc[s] = xcol[i];
+                    s++;
+                } else {                                                            /* :218 slice sum */
+                    const double *sl = cube + (size_t)i * K * K;
+                    for (int a = 0; a < K * K; a++) XtX[a] += sl[a];
+                }
+            }
+            for (int a = 0; a < K * K; a++) XtX[a] = gram[a] - XtX[a];              /* :219 */
+            for (int a = 0; a < K; a++) {                                           /* :222 */
+                double q = 0.0;
+                const double *fa = feat + (size_t)a * m;
+                for (int i = 0; i < m; i++) q += fa[i] * outc[i];
+                Xty[a] = q;
+            }
+            double *cj = C + (size_t)j * K;
+            if (alpha == 0.0) {                                                     /* :224-226 */
+                for (int a = 0; a < K; a++) XtX[a + (size_t)a * K] += lambda;
+                int rc = solve_likely_sympd(XtX, Xty, K, 1);
+                if (rc != ORACLE_OK) {
+#pragma omp critical
+                    rc_all = rc;
+                } else
+                    for (int a = 0; a < K; a++) cj[a] = Xty[a];
+            } else {                                                                /* :228 */
+                int sw = 0;
+                oracle_strong_cd(feat, outc, m, K, cj, lambda, alpha, XtX, Xty, tol, seed,
+                                 (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
+                sweeps_sum += sw;
+                for (int a = 0; a < K; a++) cj[a] = beta[a];
+            }
+            free(feat); free(outc); free(XtX); free(Xty); free(beta);
+        }
+        free(cube);
+    } else {
+        /* :234-248 shared XtX, Xty = R'X, CD on the full R */
+        if (alpha == 0.0) {
+            for (int a = 0; a < K; a++) gram[a + (size_t)a * K] += lambda;
+        }
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 100) reduction(+ : sweeps_sum)
+        for (int j = 0; j < p; j++) {
+            const double *xcol = X + (size_t)j * n;
+            double *Xty = (double *)malloc(sizeof(double) * (size_t)K);
+            double *beta = (double *)malloc(sizeof(double) * (size_t)K);
+            for (int a = 0; a < K; a++) {
+                double q = 0.0;
+                const double *ra = R + (size_t)a * n;
+                for (int i = 0; i < n; i++) q += ra[i] * xcol[i];
+                Xty[a] = q;
+            }
+            double *cj = C + (size_t)j * K;
+            if (alpha == 0.0) {                                                     /* :237-240 */
+                double *Ac = (double *)malloc(sizeof(double) * (size_t)K * K);
+                memcpy(Ac, gram, sizeof(double) * (size_t)K * K);
+                int rc = solve_likely_sympd(Ac, Xty, K, 1);
+                free(Ac);
+                if (rc != ORACLE_OK) {
+#pragma omp critical
+                    rc_all = rc;
+                } else
+                    for (int a = 0; a < K; a++) cj[a] = Xty[a];
+            } else {                                                                /* :246 */
+                int sw = 0;
+                oracle_strong_cd(R, xcol, n, K, cj, lambda, alpha, gram, Xty, tol, seed,
+                                 (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
+                sweeps_sum += sw;
+                for (int a = 0; a < K; a++) cj[a] = beta[a];
+            }
+            free(Xty); free(beta);
+        }
+    }
+    free(gram);
+    if (total_sweeps) *total_sweeps = sweeps_sum;
+    return rc_all;
+}
+
+/* ------------------------------------------------------------------------- */
+/* predict / evaluate / compute_loss — src/utils.cpp:52-102                  */
+/* ------------------------------------------------------------------------- */
+
+/* residual = X - R C   (src/optimize.cpp:320-321,377-378) */
+static void residual_from_scratch(const double *X, const double *R, const double *C, double *resid, int n, int p,
+                                  int K, int n_threads)
+{
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int j = 0; j < p; j++) {
+        double *rj = resid + (size_t)j * n;
+        const double *xj = X + (size_t)j * n;
+        const double *cj = C + (size_t)j * K;
+        for (int i = 0; i < n; i++) rj[i] = xj[i];
+        for (int k = 0; k < K; k++) {
+            double c = cj[k];
+            const double *rk = R + (size_t)k * n;
+            for (int i = 0; i < n; i++) rj[i] -= rk[i] * c;
+        }
+    }
+}
+
+/* residual += sgn * (Z_i A_i) C   (src/optimize.cpp:338,354) */
+static void residual_add_cov(double *resid, const double *A, int L, const int32_t *lev, const double *C, double sgn,
+                             int n, int p, int K, int n_threads)
+{
+    double *T = (double *)malloc(sizeof(double) * (size_t)n * K);
+    for (int k = 0; k < K; k++)
+        for (int i = 0; i < n; i++) T[i + (size_t)k * n] = A[(lev[i] - 1) + (size_t)k * L];
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int j = 0; j < p; j++) {
+        double *rj = resid + (size_t)j * n;
+        const double *cj = C + (size_t)j * K;
+        for (int k = 0; k < K; k++) {
+            double c = sgn * cj[k];
+            const double *tk = T + (size_t)k * n;
+            for (int i = 0; i < n; i++) rj[i] += tk[i] * c;
+        }
+    }
+    free(T);
+}
+
+/* evaluate — src/utils.cpp:56-77 */
+static void evaluate(const double *resid, const uint8_t *Mtr, const uint8_t *Mte, int tuning, int n, int p,
+                     double *sum_residual, double *train_rmse, double *test_rmse, int n_threads)
+{
+    double str = 0.0, ste = 0.0;
+    long long ntr = 0, nte = 0;
+    size_t tot = (size_t)n * p;
+    if (tuning == 0) {
+#pragma omp parallel for num_threads(n_threads) reduction(+ : str) schedule(static)
+        for (long long e = 0; e < (long long)tot; e++) str += resid[e] * resid[e];
+        *sum_residual = str;
+        *train_rmse = sqrt(str / ((double)n * p));
+        /* test_rmse is left uninitialised by the reference here (src/optimize.cpp:264) */
+        *test_rmse = NAN;
+        return;
+    }
+#pragma omp parallel for num_threads(n_threads) reduction(+ : str, ste, ntr, nte) schedule(static)
+    for (long long e = 0; e < (long long)tot; e++) {
+        double r2 = resid[e] * resid[e];
+        if (Mtr[e]) { str += r2; ntr++; }
+        if (Mte[e]) { ste += r2; nte++; }
+    }
+    *sum_residual = str;
+    *train_rmse = sqrt(str / (double)ntr);
+    *test_rmse = nte > 0 ? sqrt(ste / (double)nte) : NAN;
+}
+
+/* compute_loss(field) — src/utils.cpp:79-102; comps = {SSE/2, row_reg/2, col_reg/2, l1_reg} */
+static double global_loss(double *const *A, const int32_t *n_levels, int c, const double *C, int p, int K,
+                          double lambda1, double lambda2, double alpha, double sum_residual, double *comps)
+{
+    double row_reg = 0.0;
+    for (int i = 0; i < c; i++) {
+        double s = 0.0;
+        size_t cnt = (size_t)n_levels[i] * K;
+        for (size_t e = 0; e < cnt; e++) s += A[i][e] * A[i][e];
+        double nf = sqrt(s);
+        row_reg += lambda1 * nf * nf;
+    }
+    double s2 = 0.0, s1 = 0.0;
+    size_t cnt = (size_t)K * p;
+    for (size_t e = 0; e < cnt; e++) { s2 += C[e] * C[e]; s1 += fabs(C[e]); }
+    double nf = sqrt(s2);
+    double col_reg = lambda2 * (1 - alpha) * nf * nf;
+    double l1_reg = lambda2 * alpha * s1;
+    if (comps) { comps[0] = sum_residual / 2; comps[1] = row_reg / 2; comps[2] = col_reg / 2; comps[3] = l1_reg; }
+    return sum_residual / 2 + row_reg / 2 + col_reg / 2 + l1_reg;
+}
+
+/* ------------------------------------------------------------------------- */
+/* optimize — src/optimize.cpp:255-422 (categorical covariates only)          */
+/* ------------------------------------------------------------------------- */
+#define ORACLE_TRAJ_STRIDE 10
+/* traj rows: {iter, train_rmse, test_rmse, SSE/2, row_reg/2, col_reg/2, l1_reg, loss, delta_loss, decay};
+ * row 0 is the evaluation of the initial values (:320-323, iter = -1 marker),
+ * then one row per checkpoint (:381-408).                                    */
+int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c*/, int c, const int32_t *n_levels,
+                    double *const *A /*c ptrs, L_i x K, in/out*/, double *C /*K x p in/out*/, const uint8_t *Mtr,
+                    const uint8_t *Mte, int K, double lambda1, double lambda2, double alpha, int tuning,
+                    double global_tol, double sub_tol, uint32_t max_iter, uint64_t seed, int order_mode,
+                    int max_sweeps, int row_threads, int col_threads, double *out_train_rmse,
+                    double *out_test_rmse, double *out_loss, double *traj, int traj_cap, int *out_traj_rows,
+                    int *out_iters, int64_t *out_total_sweeps)
+{
+    if (tuning != 0 && tuning != 1) return ORACLE_ERR_ARG;
+    if (K < 1 || K > 64 || c < 1) return ORACLE_ERR_ARG;
+    for (int i = 0; i < c; i++)
+        for (int r = 0; r < n; r++) {
+            int32_t l = levels[r + (size_t)i * n];
+            if (l < 1 || l > n_levels[i]) return ORACLE_ERR_ARG;
+        }
+    size_t np = (size_t)n * p;
+    double *R = (double *)malloc(sizeof(double) * (size_t)n * K);
+    double *resid = (double *)malloc(sizeof(double) * np);
+    double *gram = (double *)malloc(sizeof(double) * (size_t)K * K);
+    if (!R || !resid || !gram) { free(R); free(resid); free(gram); return ORACLE_ERR_ALLOC; }
+    int rc = ORACLE_OK, trows = 0;
+    int64_t sweeps_total = 0;
+
+    /* :281-291 row_factor = sum_i A_i[level_i] */
+    for (size_t e = 0; e < (size_t)n * K; e++) R[e] = 0.0;
+    for (int i = 0; i < c; i++)
+        for (int k = 0; k < K; k++)
+            for (int r = 0; r < n; r++)
+                R[r + (size_t)k * n] += A[i][(levels[r + (size_t)i * n] - 1) + (size_t)k * n_levels[i]];
+
+    double sum_residual, train_rmse, test_rmse, loss, pre_loss, delta_loss, decay = 1.0, comps[4];
+    residual_from_scratch(X, R, C, resid, n, p, K, col_threads);                           /* :320-321 */
+    evaluate(resid, Mtr, Mte, tuning, n, p, &sum_residual, &train_rmse, &test_rmse, col_threads); /* :322 */
+    loss = global_loss(A, n_levels, c, C, p, K, lambda1, lambda2, alpha, sum_residual, comps);    /* :323 */
+    if (traj && trows < traj_cap) {
+        double *t = traj + (size_t)trows * ORACLE_TRAJ_STRIDE;
+        t[0] = -1; t[1] = train_rmse; t[2] = test_rmse; t[3] = comps[0]; t[4] = comps[1]; t[5] = comps[2];
+        t[6] = comps[3]; t[7] = loss; t[8] = NAN; t[9] = decay;
+        trows++;
+    }
+
+    uint32_t iter = 0;
+    while (iter <= max_iter) {                                                              /* :325 */
+        /* :332 gram = C C' */
+        for (int b = 0; b < K; b++)
+            for (int a = 0; a < K; a++) {
+                double s = 0.0;
+                for (int j = 0; j < p; j++) s += C[a + (size_t)j * K] * C[b + (size_t)j * K];
+                gram[a + (size_t)b * K] = s;
+            }
+        for (int i = 0; i < c && rc == ORACLE_OK; i++) {                                   /* :335 */
+            const int32_t *lev = levels + (size_t)i * n;
+            residual_add_cov(resid, A[i], n_levels[i], lev, C, +1.0, n, p, K, col_threads); /* :338 */
+            rc = oracle_optimize_row(resid, Mtr, A[i], C, lev, gram, lambda1, tuning, n, p, K, n_levels[i],
+                                     row_threads);                                          /* :339 */
+            if (i != c - 1)                                                                 /* :353-355 */
+                residual_add_cov(resid, A[i], n_levels[i], lev, C, -1.0, n, p, K, col_threads);
+        }
+        if (rc != ORACLE_OK) break;
+        /* :365-369 */
+        for (size_t e = 0; e < (size_t)n * K; e++) R[e] = 0.0;
+        for (int i = 0; i < c; i++)
+            for (int k = 0; k < K; k++)
+                for (int r = 0; r < n; r++)
+                    R[r + (size_t)k * n] += A[i][(levels[r + (size_t)i * n] - 1) + (size_t)k * n_levels[i]];
+        /* :376 */
+        int64_t sw = 0;
+        rc = oracle_optimize_col(X, Mtr, R, C, lambda2, alpha, tuning, sub_tol * decay, n, p, K, seed, iter,
+                                 order_mode, max_sweeps, col_threads, 0, &sw);
+        sweeps_total += sw;
+        if (rc != ORACLE_OK) break;
+        residual_from_scratch(X, R, C, resid, n, p, K, col_threads);                       /* :377-378 */
+
+        if (iter % 10 == 0) {                                                               /* :381-408 */
+            pre_loss = loss;
+            evaluate(resid, Mtr, Mte, tuning, n, p, &sum_residual, &train_rmse, &test_rmse, col_threads);
+            loss = global_loss(A, n_levels, c, C, p, K, lambda1, lambda2, alpha, sum_residual, comps);
+            delta_loss = pre_loss - loss;
+            if (delta_loss / 1000 <= 1e-6) decay = 1e-6;
+            else if (delta_loss / 1000 <= 1e-5) decay = 1e-5;
+            else if (delta_loss / 1000 <= 1e-4) decay = 1e-4;
+            else if (delta_loss / 1000 <= 1e-3) decay = 1e-3;
+            else if (delta_loss / 1000 <= 1e-2) decay = 1e-2;
+            else if (delta_loss / 1000 <= 1e-1) decay = 1e-1;
+            else decay = 1.0;
+            if (traj && trows < traj_cap) {
+                double *t = traj + (size_t)trows * ORACLE_TRAJ_STRIDE;
+                t[0] = iter; t[1] = train_rmse; t[2] = test_rmse; t[3] = comps[0]; t[4] = comps[1];
+                t[5] = comps[2]; t[6] = comps[3]; t[7] = loss; t[8] = delta_loss; t[9] = decay;
+                trows++;
+            }
+            if ((pre_loss - loss) / pre_loss < global_tol) break;                           /* :405-407 */
+        }
+        iter++;
+    }
+    free(R); free(resid); free(gram);
+    if (out_train_rmse) *out_train_rmse = train_rmse;
+    if (out_test_rmse) *out_test_rmse = test_rmse;
+    if (out_loss) *out_loss = loss;
+    if (out_traj_rows) *out_traj_rows = trows;
+    if (out_iters) *out_iters = (int)iter;
+    if (out_total_sweeps) *out_total_sweeps = sweeps_total;
+    return rc;
+}
+
+int oracle_num_procs(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}

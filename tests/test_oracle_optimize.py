@@ -1,0 +1,134 @@
+"""Pins the CPU oracle's block updates and outer loop (reference src/optimize.cpp:139-422, src/utils.cpp:52-102)
+against the independent numpy restatement and against mathematical identities."""
+import numpy as np
+import pytest
+
+from insider_amd import workloads as W
+from oracle import numpy_oracle as NO
+
+
+def _R(w, A):
+    return sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]))
+
+
+def _rand_factors(w, seed, scale=0.5):
+    rng = np.random.default_rng(seed)
+    A = [np.asfortranarray(rng.standard_normal(a.shape) * scale) for a in w.A0]
+    C = np.asfortranarray(rng.standard_normal(w.C0.shape) * scale)
+    return A, C
+
+
+@pytest.mark.parametrize("with_na", [False, True])
+def test_masked_gram_identities(oracle, with_na):
+    # complement form == direct sum over selected rows
+    w = W.small(with_na=with_na)
+    A, C = _rand_factors(w, 1)
+    R = _R(w, A)
+    for j in (0, 7, w.p - 1):
+        XtX, Xty = oracle.masked_gram_col(w.X[:, j], w.M_train[:, j], R)
+        sel = w.M_train[:, j] != 0
+        np.testing.assert_allclose(XtX, R[sel].T @ R[sel], atol=1e-11)
+        np.testing.assert_allclose(Xty, R[sel].T @ w.X[sel, j], atol=1e-11)
+    for r in (0, 5, w.n - 1):
+        XtX, Xty = oracle.masked_gram_row(w.X, w.M_train, r, C)
+        sel = w.M_train[r, :] != 0
+        np.testing.assert_allclose(XtX, C[:, sel] @ C[:, sel].T, atol=1e-11)
+        np.testing.assert_allclose(Xty, C[:, sel] @ w.X[r, sel], atol=1e-11)
+
+
+@pytest.mark.parametrize("tuning", [0, 1])
+def test_optimize_row_matches_numpy(oracle, tuning):
+    w = W.small(n=36, p=50, with_na=True)
+    A, C = _rand_factors(w, 2)
+    resid = w.X - _R(w, A) @ C + A[0][w.levels[:, 0] - 1, :] @ C
+    gram = C @ C.T
+    a_c = oracle.optimize_row(resid, w.M_train, A[0], C, w.levels[:, 0], gram, 1.7, tuning)
+    a_n = NO.optimize_row(resid, w.M_train, A[0], C, w.levels[:, 0], gram, 1.7, tuning)
+    np.testing.assert_allclose(a_c, a_n, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("tuning,alpha", [(1, 0.4), (1, 0.0), (0, 0.4), (0, 0.0)])
+def test_optimize_col_matches_numpy(oracle, tuning, alpha):
+    w = W.small(n=36, p=50, with_na=True)
+    A, C = _rand_factors(w, 3)
+    R = _R(w, A)
+    c_c, sw_c = oracle.optimize_col(w.X, w.M_train, R, C, 2.0, alpha, tuning, tol=1e-7, seed=5, it=2)
+    c_n, sw_n = NO.optimize_col(w.X, w.M_train, R, C, 2.0, alpha, tuning, 1e-7, seed=5, it=2)
+    assert sw_c == sw_n
+    np.testing.assert_allclose(c_c, c_n, rtol=1e-9, atol=1e-11)
+    if alpha == 0.0 and tuning == 1:  # closed-form ridge (src/optimize.cpp:224-226)
+        j = 4
+        sel = w.M_train[:, j] != 0
+        ref = np.linalg.solve(R[sel].T @ R[sel] + 2.0 * np.eye(w.K), R[sel].T @ w.X[sel, j])
+        np.testing.assert_allclose(c_c[:, j], ref, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(with_na=True), dict(interaction_idx=(1, 2)), dict(tuning=0),
+                                dict(alpha=0.0)])
+def test_optimize_matches_numpy(oracle, kw):
+    w = W.small(**kw)
+    res_c = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                            tuning=w.tuning, max_iter=11, seed=42)
+    res_n = NO.optimize(w.X, w.A0, w.C0, w.levels, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=w.tuning,
+                        max_iter=11, seed=42)
+    assert res_c["iters"] == res_n["iters"] and res_c["total_sweeps"] == res_n["total_sweeps"]
+    np.testing.assert_allclose(res_c["traj"], res_n["traj"], rtol=1e-9, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(res_c["column_factor"], res_n["column_factor"], rtol=1e-8, atol=1e-10)
+    for a, b in zip(res_c["row_matrices"], res_n["row_matrices"]):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-10)
+    assert res_c["loss"] == pytest.approx(res_n["loss"], rel=1e-10)
+    if w.tuning == 0:
+        assert np.isnan(res_c["test_rmse"])  # uninitialised in the reference (src/optimize.cpp:264)
+
+
+def test_loss_components_and_monotone(oracle):
+    # checkpoint losses non-increasing; components recomputed independently from the factors
+    w = W.small(n=60, p=90, K=5)
+    res = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          max_iter=30, seed=1)
+    tr = res["traj"]
+    assert list(tr[:, 0]) == [-1, 0, 10, 20, 30] and res["iters"] == 31   # iter <= max_iter (src/optimize.cpp:325)
+    assert np.all(np.diff(tr[:, 7]) <= 1e-9)
+    A, C = res["row_matrices"], res["column_factor"]
+    resid = w.X - _R(w, A) @ C
+    sse = np.sum(resid[w.M_train != 0] ** 2)
+    assert tr[-1, 3] == pytest.approx(sse / 2, rel=1e-11)
+    assert tr[-1, 4] == pytest.approx(w.lam * sum(np.sum(a ** 2) for a in A) / 2, rel=1e-11)
+    assert tr[-1, 5] == pytest.approx(w.lam * (1 - w.alpha) * np.sum(C ** 2) / 2, rel=1e-11)
+    assert tr[-1, 6] == pytest.approx(w.lam * w.alpha * np.sum(np.abs(C)), rel=1e-11)
+    assert res["test_rmse"] == pytest.approx(np.sqrt(np.mean(resid[w.M_test != 0] ** 2)), rel=1e-11)
+    assert res["train_rmse"] == pytest.approx(np.sqrt(sse / np.count_nonzero(w.M_train)), rel=1e-11)
+
+
+def test_all_ones_mask_equals_unmasked(oracle):
+    # tuning=1 with M == 1 must equal tuning=0
+    w = W.small(f=0.0)
+    assert w.M_train.all()
+    kw = dict(max_iter=10, seed=3)
+    r1 = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                         tuning=1, **kw)
+    r0 = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                         tuning=0, **kw)
+    np.testing.assert_allclose(r1["column_factor"], r0["column_factor"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(r1["traj"][:, 3:8], r0["traj"][:, 3:8], rtol=1e-9)
+
+
+def test_decay_schedule_and_global_tol(oracle):
+    w = W.small()
+    res = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          max_iter=200, global_tol=1e-3, seed=1)
+    tr = res["traj"]
+    # stops at the first checkpoint whose relative improvement is < global_tol (src/optimize.cpp:405)
+    rel = (tr[:-1, 7] - tr[1:, 7]) / tr[:-1, 7]
+    assert rel[-1] < 1e-3 and np.all(rel[:-1] >= 1e-3)
+    for d, dec in zip(tr[1:, 8], tr[1:, 9]):   # src/optimize.cpp:389-403
+        exp = next((t for t in (1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1) if d / 1000 <= t), 1.0)
+        assert dec == exp
+
+
+def test_bad_level_ids_rejected(oracle):
+    w = W.small()
+    lev = w.levels.copy()
+    lev[0, 0] = 0
+    with pytest.raises(RuntimeError):
+        oracle.optimize(w.X, lev, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, 1, 1, 0.1, max_iter=1)
