@@ -1,0 +1,147 @@
+/*
+ * insider_hip.h — C ABI of libinsider_hip.so, the MI355X-native INSIDER
+ * factorisation core.
+ *
+ * This is the drop-in boundary for the reference's Rcpp exports
+ * (/root/reference/src/RcppExports.cpp:112-124, R/RcppExports.R:4-22): plain
+ * pointers and sizes, no SEXP / Rcpp / Armadillo / torch types.  All host
+ * matrices are column-major fp64 exactly as R hands them to the reference
+ * (zero-copy views, src/optimize.cpp:283-284); masks are uint8 instead of the
+ * reference's fp64 copies (src/RcppExports.cpp:96-97); level ids are int32,
+ * 1-based, exactly 1..L_i per covariate (src/optimize.cpp:175,286 index rows as
+ * level-1; validated here, status INSIDER_ERR_ARG otherwise).
+ *
+ * Error model: every entry point returns an int status (0 = ok) and never
+ * calls exit() (the reference does on bad `tuning`, src/optimize.cpp:249-251,
+ * 270-272); insider_hip_last_error() returns the message of the calling
+ * thread's last failure.  The library fails loudly (INSIDER_ERR_NO_DEVICE)
+ * when no HIP device is present: there is no CPU fallback.
+ */
+#ifndef INSIDER_HIP_H
+#define INSIDER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INSIDER_OK 0
+#define INSIDER_ERR_ARG 1        /* bad argument (tuning not in {0,1}, level ids not 1..L_i, K out of range, ...) */
+#define INSIDER_ERR_SOLVE 2      /* a ridge normal-equation system was not positive definite */
+#define INSIDER_ERR_ALLOC 3      /* host or device allocation failed */
+#define INSIDER_ERR_HIP 4        /* HIP runtime error (message has the call) */
+#define INSIDER_ERR_NO_DEVICE 5  /* no HIP device / extension unusable: no fallback exists */
+#define INSIDER_ERR_UNSUPPORTED 6 /* e.g. continuous covariates (inc_continuous = 1), K > 63 */
+#define INSIDER_ERR_COMM 7       /* the all-reduce callback reported failure */
+
+/* Largest latent dimension the kernels support (K + 1 augmented column <= 64). */
+#define INSIDER_MAX_K 63
+
+/* Number of doubles per trajectory row written by insider_hip_optimize():
+ * {iter, train_rmse, test_rmse, SSE/2, row_reg/2, col_reg/2, l1_reg, loss, delta_loss, decay}.
+ * Row 0 is the evaluation of the initial values (iter = -1; src/optimize.cpp:320-323); one row per
+ * checkpoint follows (iter % 10 == 0; src/optimize.cpp:381-408).  These are the quantities the reference
+ * prints to stdout (src/utils.cpp:70-76,95-100). */
+#define INSIDER_TRAJ_STRIDE 10
+
+typedef struct insider_hip_handle insider_hip_handle;
+
+/* Sum-all-reduce of `count` doubles at device pointer `dev_buf`, in place, across the gene-sharded ranks.
+ * Called by insider_hip_optimize() on the calling thread after the producing kernels have completed
+ * (the stream is synchronised before the call); must return 0 on success after the reduced values are
+ * visible in dev_buf to subsequent work on any stream. */
+typedef int (*insider_allreduce_fn)(void *user, double *dev_buf, int64_t count);
+
+const char *insider_hip_version(void);
+const char *insider_hip_last_error(void);
+/* Number of visible HIP devices (0 if none); does not create a context. */
+int insider_hip_device_count(void);
+
+/*
+ * Upload one data set (or one gene slab of it) to HBM and precompute everything that does not depend on the
+ * factors: the combined uint8 mask codes, transposed copies for the row-side pass, per-level row sums of X,
+ * per-gene sums of squares.  Replaces the per-call marshaling of src/RcppExports.cpp:91-97 — tune()'s grid
+ * (R/insider.R:142-174) re-uploads nothing but the inits.
+ *   X        n x p column-major fp64 (NA entries must hold 0, R/insider.R:26)
+ *   levels   n x c column-major int32, 1-based ids (cfd_indicators, src/optimize.cpp:256)
+ *   n_levels c entries, L_i
+ *   M_train  n x p uint8 (train_indicator), M_test n x p uint8 (test_indicator); an entry with both 0 is NA
+ *   device   HIP device ordinal
+ */
+int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *levels, int c, const int32_t *n_levels,
+                       const uint8_t *M_train, const uint8_t *M_test, int device, insider_hip_handle **out);
+void insider_hip_destroy(insider_hip_handle *h);
+
+/* Gene-axis sharding: this handle holds genes [gene_offset, gene_offset + p) of the global
+ * matrix.  gene_offset keys the per-gene sweep order so results do not depend on the sharding.  `fn` (may be
+ * NULL when world == 1) is called once per covariate per outer iteration (level normal equations) and once
+ * per checkpoint (loss terms). */
+int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, int world, insider_allreduce_fn fn,
+                          void *user);
+
+/* Options: "max_sweeps" (per elastic-net subproblem, default 10000), "order_mode" (0 = hashed random order of
+ * include/insider_perm.h, 1 = cyclic), "profile" (1 = time the streaming kernels with HIP events),
+ * "verbose" (1 = print the reference's per-checkpoint lines to stdout). */
+int insider_hip_set_option(insider_hip_handle *h, const char *name, double value);
+
+/*
+ * The reference's optimize() (src/optimize.cpp:255-422; .Call symbol _insider_optimize,
+ * src/RcppExports.cpp:87-110) for categorical covariates.  Same argument meaning:
+ *   A            c pointers, A[i] is L_i x K column-major, IN/OUT (the reference mutates cfd_factors in place,
+ *                src/optimize.cpp:283-284)
+ *   C            K x p column-major, IN/OUT (column_factor, mat&)
+ *   lambda1/lambda2/alpha/tuning/global_tol/sub_tol/max_iter as src/optimize.cpp:256-257
+ *                (max_iter + 1 outer iterations are run: `iter <= max_iter`, :325)
+ *   seed         replaces Rcpp::RNGScope / R's global RNG (src/RcppExports.cpp:90)
+ *   out_*        train_rmse, test_rmse (NaN when tuning = 0: uninitialised in the reference, :264), loss
+ *   traj         optional, traj_cap rows of INSIDER_TRAJ_STRIDE doubles; out_traj_rows rows written
+ *   out_iters    value of `iter` when the loop ended
+ * inc_continuous = 1 (ctns_confounder) is not supported yet: pass 0 (INSIDER_ERR_UNSUPPORTED otherwise).
+ */
+int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K,
+                         double lambda1, double lambda2, double alpha, int tuning, double global_tol, double sub_tol,
+                         uint32_t max_iter, uint64_t seed, double *out_train_rmse, double *out_test_rmse,
+                         double *out_loss, double *traj, int traj_cap, int *out_traj_rows, int *out_iters);
+
+/* One-shot form with the reference's 16 logical arguments (create + optimize + destroy). */
+int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *const *A, double *C,
+                                 const int32_t *levels, int c, const int32_t *n_levels, const uint8_t *M_train,
+                                 const uint8_t *M_test, int inc_continuous, int K, double lambda1, double lambda2,
+                                 double alpha, int tuning, double global_tol, double sub_tol, uint32_t max_iter,
+                                 uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss);
+
+/*
+ * strong_coordinate_descent (src/coordinate_descent.cpp:56-127; .Call symbol
+ * _insider_strong_coordinate_descent, src/RcppExports.cpp:35-50), batched: nprob independent K-variable
+ * elastic-net subproblems, one wavefront each, solved in covariance form from (XtX, Xty) — the design
+ * matrix X and outcome y of the reference signature enter only through XtX = X'X and Xty = X'y, which the
+ * reference's callers always pass alongside (src/optimize.cpp:228,246), so they are not taken here.
+ *   XtX    nprob blocks of K x K (column-major; symmetric), Xty / wstart / beta_out nprob blocks of K
+ *   unit0  subproblem b uses sweep-order key unit0 + b;  sweeps_out optional, nprob ints
+ */
+int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob,
+                          double lambda, double alpha, double tol, uint64_t seed, uint32_t unit0, uint32_t iter,
+                          int order_mode, int max_sweeps, int device, double *beta_out, int32_t *sweeps_out);
+
+/*
+ * The masked Gram / XtY reductions on their own (for parity tests and profiling).
+ * Column side (src/optimize.cpp:216-222): for every gene j, XtX_j = R'R - sum_{i: M_train[i,j]=0} r_i r_i',
+ * Xty_j = sum_i M_train[i,j] x_ij r_i.   R is n x K column-major (row_factor).
+ *   G_out  p blocks of K x K column-major, q_out p blocks of K.
+ * Row side (src/optimize.cpp:162-171 with the data matrix in place of the Gauss-Seidel residual): for every
+ * sample r, XtX_r = CC' - sum_{j: M_train[r,j]=0} c_j c_j', Xty_r = sum_j M_train[r,j] x_rj c_j.
+ *   C is K x p column-major;  H_out n blocks of K x K, b_out n blocks of K.
+ */
+int insider_hip_masked_gram_cols(insider_hip_handle *h, const double *R, int K, double *G_out, double *q_out);
+int insider_hip_masked_gram_rows(insider_hip_handle *h, const double *C, int K, double *H_out, double *b_out);
+
+/* Profile of the last insider_hip_optimize() call (option "profile" = 1).  out[0..7]:
+ * {col kernel launches, col kernel total ms, row kernel launches, row kernel total ms,
+ *  total optimize wall ms, outer iterations run, elastic-net sweeps total, reserved}. */
+int insider_hip_get_profile(insider_hip_handle *h, double *out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSIDER_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libinsider_hip.so (the C ABI declared in include/insider_hip.h).
+
+There is no CPU fallback: every compute entry point raises InsiderError when the
+shared library is missing or no HIP device is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinsider_hip.so")
+
+OK, ERR_ARG, ERR_SOLVE, ERR_ALLOC, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_COMM = range(8)
+TRAJ_STRIDE = 10
+MAX_K = 63
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+# every symbol include/insider_hip.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "insider_hip_version", "insider_hip_last_error", "insider_hip_device_count", "insider_hip_create",
+    "insider_hip_destroy", "insider_hip_set_shard", "insider_hip_set_option", "insider_hip_optimize",
+    "insider_hip_optimize_oneshot", "insider_hip_strong_cd", "insider_hip_masked_gram_cols",
+    "insider_hip_masked_gram_rows", "insider_hip_get_profile",
+)
+
+
+class InsiderError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"insider_hip status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load libinsider_hip.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise InsiderError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                                          f"g.build()'` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    dp, i32p, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    lib.insider_hip_version.restype = C.c_char_p
+    lib.insider_hip_last_error.restype = C.c_char_p
+    lib.insider_hip_device_count.restype = C.c_int
+    lib.insider_hip_create.argtypes = [dp, C.c_int64, C.c_int64, i32p, C.c_int, i32p, u8p, u8p, C.c_int,
+                                       C.POINTER(C.c_void_p)]
+    lib.insider_hip_destroy.argtypes = [C.c_void_p]
+    lib.insider_hip_destroy.restype = None
+    lib.insider_hip_set_shard.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
+    lib.insider_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    lib.insider_hip_optimize.argtypes = [C.c_void_p, C.POINTER(dp), dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                         C.c_double, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint64, dp, dp,
+                                         dp, dp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.insider_hip_optimize_oneshot.argtypes = [dp, C.c_int64, C.c_int64, C.POINTER(dp), dp, i32p, C.c_int, i32p,
+                                                 u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                 C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint64, dp, dp, dp]
+    lib.insider_hip_strong_cd.argtypes = [dp, dp, dp, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                          C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, dp, i32p]
+    lib.insider_hip_masked_gram_cols.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]
+    lib.insider_hip_masked_gram_rows.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]
+    lib.insider_hip_get_profile.argtypes = [C.c_void_p, dp]
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        raise InsiderError(status, load().insider_hip_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return int(load().insider_hip_device_count())
+
+
+def f64(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def ptr(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))

@@ -1,0 +1,353 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Operator level (names and argument meaning of /root/reference/R/RcppExports.R:4-22):
+    optimize(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, train_indicator,
+             test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning, global_tol,
+             sub_tol, max_iter)
+    strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol)
+Caller level (R/insider.R:18-216, R/utils.R:40-43,78-117) — R is absent from this pipeline, so the R S3 API is
+mirrored here in Python with the same names, defaults and error behaviour:
+    insider(), tune(), fit(), ratio_splitter(), init_parameters()
+
+All compute goes through libinsider_hip.so (insider_amd/_lib.py); nothing here falls back to the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import InsiderError
+
+DEFAULT_SEED = 0x1D5EED
+
+
+class InsiderData:
+    """A data set resident in HBM (insider_hip_create). Reused across optimize() calls, e.g. by tune()'s grid."""
+
+    def __init__(self, data, cfd_indicators, train_indicator, test_indicator, device=0, n_levels=None):
+        lib = _lib.load()
+        X = _lib.f64(data)
+        n, p = X.shape
+        lev = np.asfortranarray(np.asarray(cfd_indicators).reshape(n, -1), dtype=np.int32)
+        c = lev.shape[1]
+        if n_levels is None:
+            # R/insider.R:107: factor_num <- length(unique(confounder[, i])); ids must be exactly 1..L_i
+            n_levels = np.array([len(np.unique(lev[:, i])) for i in range(c)], dtype=np.int32)
+        n_levels = np.ascontiguousarray(n_levels, dtype=np.int32)
+        Mtr = np.asfortranarray(train_indicator, dtype=np.uint8)
+        Mte = np.asfortranarray(test_indicator, dtype=np.uint8)
+        if Mtr.shape != (n, p) or Mte.shape != (n, p):
+            raise InsiderError(_lib.ERR_ARG, "indicator shape must match data")
+        self.n, self.p, self.c = n, p, c
+        self.n_levels = n_levels
+        self._h = C.c_void_p()
+        _lib.check(lib.insider_hip_create(_lib.ptr(X), n, p, _lib.ptr(lev, C.c_int32), c, _lib.ptr(n_levels, C.c_int32),
+                                          _lib.ptr(Mtr, C.c_uint8), _lib.ptr(Mte, C.c_uint8), int(device),
+                                          C.byref(self._h)))
+        self._cb = None  # keeps the ctypes callback alive
+
+    def set_option(self, name, value):
+        _lib.check(_lib.load().insider_hip_set_option(self._h, name.encode(), float(value)))
+
+    def set_shard(self, gene_offset, rank, world, allreduce=None):
+        """allreduce(ptr:int, count:int) -> None sums `count` doubles at device pointer `ptr` across ranks in place."""
+        if allreduce is None:
+            cb = C.cast(None, _lib.ALLREDUCE_FN)
+        else:
+            def _tramp(_user, ptr, count):
+                try:
+                    allreduce(int(ptr), int(count))
+                    return 0
+                except Exception as e:  # never unwind through the C frame
+                    print(f"[insider_amd] all-reduce callback failed: {e!r}", flush=True)
+                    return 1
+            cb = _lib.ALLREDUCE_FN(_tramp)
+        self._cb = cb
+        _lib.check(_lib.load().insider_hip_set_shard(self._h, int(gene_offset), int(rank), int(world), cb, None))
+
+    def optimize(self, cfd_factors, column_factor, latent_dim, lambda1=1.0, lambda2=1.0, alpha=0.1, tuning=1,
+                 global_tol=1e-10, sub_tol=1e-5, max_iter=10000, seed=DEFAULT_SEED, inc_continuous=0, traj_cap=4096):
+        lib = _lib.load()
+        K = int(latent_dim)
+        A = []
+        for i, a in enumerate(cfd_factors):
+            a = np.asarray(a)
+            if a.shape != (int(self.n_levels[i]), K):
+                raise InsiderError(_lib.ERR_ARG, f"cfd_factors[{i}] must be {int(self.n_levels[i])} x {K}")
+            A.append(a if (a.dtype == np.float64 and a.flags.f_contiguous) else _lib.f64(a).copy(order="F"))
+        Cm = np.asarray(column_factor)
+        if Cm.shape != (K, self.p):
+            raise InsiderError(_lib.ERR_ARG, f"column_factor must be {K} x {self.p}")
+        Cw = Cm if (Cm.dtype == np.float64 and Cm.flags.f_contiguous) else _lib.f64(Cm).copy(order="F")
+        Aptrs = (C.POINTER(C.c_double) * self.c)(*[_lib.ptr(a) for a in A])
+        traj = np.full((traj_cap, _lib.TRAJ_STRIDE), np.nan)
+        tr, te, lo = C.c_double(), C.c_double(), C.c_double()
+        rows, iters = C.c_int(), C.c_int()
+        _lib.check(lib.insider_hip_optimize(self._h, Aptrs, _lib.ptr(Cw), int(inc_continuous), K, float(lambda1),
+                                            float(lambda2), float(alpha), int(tuning), float(global_tol),
+                                            float(sub_tol), int(max_iter), int(seed), C.byref(tr), C.byref(te),
+                                            C.byref(lo), _lib.ptr(traj), traj_cap, C.byref(rows), C.byref(iters)))
+        # the reference mutates cfd_factors / column_factor in place AND returns copies (src/optimize.cpp:283-284,413)
+        for src, dst in zip(A, cfd_factors):
+            if src is not dst and isinstance(dst, np.ndarray):
+                dst[...] = src
+        if Cw is not column_factor and isinstance(column_factor, np.ndarray):
+            column_factor[...] = Cw
+        return dict(row_matrices={f"factor{i}": a.copy() for i, a in enumerate(A)}, column_factor=Cw.copy(),
+                    train_rmse=tr.value, test_rmse=te.value, loss=lo.value, traj=traj[: rows.value].copy(),
+                    iters=iters.value)
+
+    def masked_gram_cols(self, R):
+        R = _lib.f64(R)
+        K = R.shape[1]
+        G = np.zeros((self.p, K, K))
+        q = np.zeros((self.p, K))
+        _lib.check(_lib.load().insider_hip_masked_gram_cols(self._h, _lib.ptr(R), K, _lib.ptr(G), _lib.ptr(q)))
+        return G, q
+
+    def masked_gram_rows(self, Cmat):
+        Cmat = _lib.f64(Cmat)
+        K = Cmat.shape[0]
+        H = np.zeros((self.n, K, K))
+        b = np.zeros((self.n, K))
+        _lib.check(_lib.load().insider_hip_masked_gram_rows(self._h, _lib.ptr(Cmat), K, _lib.ptr(H), _lib.ptr(b)))
+        return H, b
+
+    def profile(self):
+        out = np.zeros(8)
+        _lib.check(_lib.load().insider_hip_get_profile(self._h, _lib.ptr(out)))
+        return dict(col_launches=int(out[0]), col_ms=out[1], row_launches=int(out[2]), row_ms=out[3],
+                    wall_ms=out[4], iters=int(out[5]), sweeps=int(out[6]))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.load().insider_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# operator level — R/RcppExports.R:4-22
+# ---------------------------------------------------------------------------------------------------------------
+def optimize(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, train_indicator, test_indicator,
+             inc_continuous, latent_dim, lambda1=1.0, lambda2=1.0, alpha=0.1, tuning=1, global_tol=1e-10, sub_tol=1e-5,
+             max_iter=10000, seed=DEFAULT_SEED, device=0):
+    """optimize() of R/RcppExports.R:20-22 (src/optimize.cpp:255-422): one-shot upload + fit.
+
+    Returns dict(row_matrices, column_factor, train_rmse, test_rmse, loss) like the reference's List (:417-421);
+    float64 Fortran-ordered ``cfd_factors`` / ``column_factor`` arrays are also updated in place.
+    """
+    if tuning not in (0, 1):
+        raise InsiderError(_lib.ERR_ARG, "Parameter tuning should be either 0 or 1!")
+    if inc_continuous not in (0, 1):
+        raise InsiderError(_lib.ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.")
+    ds = InsiderData(data, cfd_indicators, train_indicator, test_indicator, device=device)
+    try:
+        return ds.optimize(cfd_factors, column_factor, latent_dim, lambda1, lambda2, alpha, tuning, global_tol, sub_tol,
+                           max_iter, seed, inc_continuous)
+    finally:
+        ds.close()
+
+
+def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol=1e-5, seed=DEFAULT_SEED, unit=0, it=0,
+                              order_mode=0, max_sweeps=10000, device=0, return_sweeps=False):
+    """strong_coordinate_descent() of R/RcppExports.R:8-10 (src/coordinate_descent.cpp:56-127).
+
+    ``X`` and ``y`` are accepted for signature parity; the solver works in covariance form on ``XtX`` / ``Xty``
+    (which the reference's signature already carries).  Batched use: pass XtX of shape (B, K, K) and Xty / wstart of
+    shape (B, K).
+    """
+    G = np.ascontiguousarray(XtX, dtype=np.float64)
+    q = np.ascontiguousarray(Xty, dtype=np.float64)
+    w = np.ascontiguousarray(wstart, dtype=np.float64)
+    single = G.ndim == 2
+    if single:
+        G, q, w = G[None], q[None], w[None]
+    B, K = q.shape
+    if G.shape != (B, K, K) or w.shape != (B, K):
+        raise InsiderError(_lib.ERR_ARG, "XtX must be (B,K,K) and Xty/wstart (B,K)")
+    beta = np.zeros((B, K))
+    sw = np.zeros(B, dtype=np.int32)
+    _lib.check(_lib.load().insider_hip_strong_cd(_lib.ptr(G), _lib.ptr(q), _lib.ptr(w), K, B, float(lambda_),
+                                                 float(alpha), float(tol), int(seed), int(unit), int(it),
+                                                 int(order_mode), int(max_sweeps), int(device), _lib.ptr(beta),
+                                                 _lib.ptr(sw, C.c_int32)))
+    if single:
+        beta, sw = beta[0], int(sw[0])
+    return (beta, sw) if return_sweeps else beta
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# caller level — R/insider.R, R/utils.R
+# ---------------------------------------------------------------------------------------------------------------
+def init_parameters(size, init_mean=0.0, init_std=0.001, rng=None):
+    """R/utils.R:40-43: rnorm(size, mean, sd). ``rng`` replaces R's global RNG."""
+    rng = rng if rng is not None else np.random.default_rng()
+    return rng.normal(init_mean, init_std, size=size)
+
+
+def ratio_splitter(data, ratio=0.1, rm_na_col=True, seed=123):
+    """R/utils.R:78-117: element-wise hold-out without replacement; NA -> 0 and excluded; all-zero columns of the
+    train set dropped.  (numpy PCG64 stands in for R's set.seed(123); sample().)"""
+    data = np.array(data, dtype=np.float64, order="F")
+    na = np.isnan(data)
+    data[na] = 0.0
+    train = ~na
+    rng = np.random.Generator(np.random.PCG64(seed))
+    existing = np.flatnonzero((~na).ravel(order="F"))
+    k = int(np.floor(existing.size * ratio))
+    test_idx = rng.choice(existing, size=k, replace=False)
+    test = np.zeros(data.size, dtype=bool)
+    test[test_idx] = True
+    test = test.reshape(data.shape, order="F")
+    testset = np.where(test, data, 0.0)
+    trainset = np.where(test, 0.0, data)
+    train &= ~test
+    num_per_col = (trainset != 0).sum(axis=0)
+    print(f"number of all zero columns removed: {int((num_per_col == 0).sum())}")
+    keep = num_per_col != 0 if rm_na_col else np.ones(data.shape[1], dtype=bool)
+    return dict(trainset=trainset[:, keep], testset=testset[:, keep], train_indicator=train[:, keep],
+                test_indicator=test[:, keep], na_indicator=na[:, keep], kept_columns=keep)
+
+
+class Insider(dict):
+    """The reference's S3 object of class "insider" (a list, R/insider.R:24)."""
+
+
+def insider(data, confounder, ctns_confounder=None, interaction_idx=None, split_ratio=0.1, global_tol=1e-9,
+            sub_tol=1e-5, tuning_iter=30, max_iter=50000, device=0, seed=DEFAULT_SEED):
+    """insider() of R/insider.R:18-67."""
+    data = np.asarray(data, dtype=np.float64)
+    confounder = np.asarray(confounder)
+    if confounder.ndim == 1:
+        confounder = confounder[:, None]
+    dataset = ratio_splitter(data, ratio=split_ratio)
+    obj = Insider()
+    keep = dataset["kept_columns"]
+    d = np.array(data[:, keep], dtype=np.float64, order="F")
+    d[np.isnan(d)] = 0.0                                      # R/insider.R:26 (intent: NA -> 0)
+    obj["data"] = d
+    if interaction_idx is not None and len(interaction_idx) > 1 and \
+            all(isinstance(v, (int, np.integer)) for v in interaction_idx):
+        if max(interaction_idx) > confounder.shape[1]:
+            raise ValueError("The interaction_idx is out of the range of confounder!")   # R/insider.R:30-32
+        from .workloads import interaction_indicator
+        obj["confounder"] = interaction_indicator(confounder.astype(np.int32), tuple(interaction_idx))  # :34-40
+    elif interaction_idx is None:
+        obj["confounder"] = np.asfortranarray(confounder, dtype=np.int32)                 # :43
+    else:
+        raise ValueError("The interaction_idx should be integers and its length must be greater than or equal to 2!")
+    if ctns_confounder is not None:
+        obj["inc_continuous"] = 1
+        obj["ctns_confounder"] = np.asarray(ctns_confounder, dtype=np.float64)
+    else:
+        obj["inc_continuous"] = 0
+        obj["ctns_confounder"] = np.zeros((confounder.shape[0], 1))
+    obj["train_indicator"] = np.asfortranarray(dataset["train_indicator"], dtype=np.uint8)   # :57-59
+    obj["test_indicator"] = np.asfortranarray(dataset["test_indicator"], dtype=np.uint8)
+    obj["na_indicator"] = np.asfortranarray(dataset["na_indicator"], dtype=np.uint8)
+    obj["params"] = dict(global_tol=global_tol, sub_tol=sub_tol, tuning_iter=tuning_iter, max_iter=max_iter)
+    obj["device"] = device
+    obj["seed"] = seed
+    return obj
+
+
+def _resident(obj, which):
+    """HBM-resident data set for the tune (train/test masks) or fit (train+test / NA masks) call pattern."""
+    key = "_resident_" + which
+    if key not in obj:
+        if which == "tune":
+            tr, te = obj["train_indicator"], obj["test_indicator"]
+        else:  # R/insider.R:207-208: indicator = train + test, "test" = NA mask
+            tr, te = obj["train_indicator"] + obj["test_indicator"], obj["na_indicator"]
+        obj[key] = InsiderData(obj["data"], obj["confounder"], tr, te, device=obj.get("device", 0))
+    return obj[key]
+
+
+def _fresh_inits(obj, latent_rank, rng):
+    conf = obj["confounder"]
+    cfd = [np.asfortranarray(init_parameters(len(np.unique(conf[:, i])) * latent_rank, rng=rng)
+                             .reshape((-1, latent_rank), order="F")) for i in range(conf.shape[1])]     # :106-109
+    if obj["inc_continuous"] == 1:
+        cfd.append(np.asfortranarray(init_parameters(obj["ctns_confounder"].shape[1] * latent_rank, rng=rng)
+                                     .reshape((-1, latent_rank), order="F")))                            # :111-113
+    col = np.asfortranarray(init_parameters(latent_rank * obj["data"].shape[1], rng=rng)
+                            .reshape((latent_rank, -1), order="F"))                                      # :114
+    return cfd, col
+
+
+def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None):
+    """tune() of R/insider.R:81-176.  ``out_dir``: where to write the reference's CSVs (None = do not write)."""
+    lat = np.atleast_1d(latent_dimension) if latent_dimension is not None else np.array([])
+    lam = np.atleast_1d(np.asarray(lambda_, dtype=float))
+    alp = np.atleast_1d(np.asarray(alpha, dtype=float))
+    if lat.size == 0 or not np.issubdtype(lat.dtype, np.integer):
+        raise ValueError("TUNNING: The element of latent_dimension, lambda, and alpha should be integer, numeric, "
+                         "and numeric.")                                                                 # :83-85
+    if lat.size <= 1 and lam.size <= 1 and alp.size <= 1:
+        raise ValueError("TUNNING: The length of either latent_dimension or lambda and alpha should be greater "
+                         "than 1.")                                                                      # :87-89
+    prm = obj["params"]
+    rng = rng if rng is not None else np.random.default_rng(obj.get("seed", DEFAULT_SEED))
+    ds = _resident(obj, "tune")
+    rank_tuning, reg_tuning = None, None
+    if lat.size > 1:                                                                                     # :98-132
+        rows = []
+        for latent_rank in lat:
+            print(f"Latent rank:  {int(latent_rank)} ---------------------------------")
+            cfd, col = _fresh_inits(obj, int(latent_rank), rng)
+            if lam.size == 1 and alp.size == 1:
+                l_, a_ = float(lam[0]), float(alp[0])
+            else:
+                l_, a_ = 0.1, 0.0                                                                        # :120-121
+            fitted = ds.optimize(cfd, col, int(latent_rank), l_, l_, a_, 1, prm["global_tol"], prm["sub_tol"],
+                                 prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
+                                 inc_continuous=obj["inc_continuous"])
+            rows.append((int(latent_rank), fitted["train_rmse"], fitted["test_rmse"]))
+            rank_tuning = np.array(rows)
+            if out_dir is not None:
+                np.savetxt(os.path.join(out_dir, "insider_rank_tuning_result.csv"), rank_tuning, delimiter=",")
+        latent_rank = int(lat[int(np.argmin(rank_tuning[:, 2]))])                                        # :136
+    else:
+        latent_rank = int(lat[0])
+    if lam.size > 1 or alp.size > 1:                                                                     # :142-174
+        rows = []
+        for a_ in alp:                      # expand.grid(lambda, alpha): lambda varies fastest
+            for l_ in lam:
+                l_r, a_r = round(float(l_), 2), round(float(a_), 2)                                      # :149-150
+                print(f"parameter grid: {l_r},{a_r} ---------------------------------")
+                cfd, col = _fresh_inits(obj, latent_rank, rng)
+                fitted = ds.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
+                                     prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
+                                     inc_continuous=obj["inc_continuous"])
+                rows.append((l_r, a_r, fitted["train_rmse"], fitted["test_rmse"]))
+                reg_tuning = np.array(rows)
+                if out_dir is not None:
+                    np.savetxt(os.path.join(out_dir, f"insider_R{latent_rank}_reg_tuning_result.csv"), reg_tuning,
+                               delimiter=",")
+    return dict(rank_tuning=rank_tuning, latent_rank=latent_rank, reg_tuning=reg_tuning)
+
+
+def fit(obj, latent_dimension=None, lambda_=None, alpha=None, partition=0, rng=None):
+    """fit() of R/insider.R:190-216."""
+    prm = obj["params"]
+    rng = rng if rng is not None else np.random.default_rng(obj.get("seed", DEFAULT_SEED))
+    K = int(latent_dimension)
+    cfd, col = _fresh_inits(obj, K, rng)
+    ds = _resident(obj, "fit")
+    fitted = ds.optimize(cfd, col, K, float(lambda_), float(lambda_), float(alpha), int(partition), prm["global_tol"],
+                         prm["sub_tol"], prm["max_iter"], seed=obj.get("seed", DEFAULT_SEED),
+                         inc_continuous=obj["inc_continuous"])
+    obj["cfd_matrices"] = fitted["row_matrices"]                                                         # :211-213
+    obj["column_factor"] = fitted["column_factor"]
+    obj["test_rmse"] = fitted["test_rmse"]
+    obj["train_rmse"] = fitted["train_rmse"]
+    obj["loss"] = fitted["loss"]
+    obj["traj"] = fitted["traj"]
+    return obj

@@ -1,0 +1,870 @@
+// insider_hip.hip — host driver and C ABI of libinsider_hip.so (see include/insider_hip.h).
+//
+// The outer alternating loop is the reference's optimize() (src/optimize.cpp:255-422) re-derived as
+// "statistics, then solve" (DESIGN.md section 2): two streaming passes over (X, mask codes) per outer iteration
+// — one per sample for the row update, one per gene fused with the elastic-net solve — and a handful of small
+// dense kernels.  Everything is enqueued on one HIP stream; the host synchronises only at the reference's loss
+// checkpoints (every 10th iteration) and around the optional cross-rank all-reduce.
+#include "insider_kernels.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/insider_hip.h"
+
+using namespace insider;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHECK(call)                                                                                  \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? INSIDER_ERR_ALLOC : INSIDER_ERR_HIP,                \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+#define KCHECK() HIPCHECK(hipGetLastError())
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+template <typename T>
+int dmalloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHECK(hipMalloc((void **)p, count * sizeof(T)));
+    return INSIDER_OK;
+}
+
+struct CovTables {   // per covariate, device
+    int L = 0, nchunks = 0;
+    int *chunk_level = nullptr, *chunk_begin = nullptr, *chunk_end = nullptr, *lvl_chunk_ptr = nullptr;
+};
+
+constexpr int LEVEL_CHUNK = 16;
+
+}  // namespace
+
+struct insider_hip_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0, p = 0, ldn = 0, ldp = 0;
+    int c = 0, SL = 0, SLP = 0;
+    std::vector<int> n_levels, lvl_off;   // lvl_off has c + 1 entries
+    // data-set state (device)
+    double *X = nullptr, *Xt = nullptr;
+    uint8_t *codes = nullptr, *codes_t = nullptr;
+    int *lev = nullptr, *lvl_off_d = nullptr, *members_all = nullptr, *lvl_ptr_all = nullptr, *lvl_count_all = nullptr;
+    std::vector<CovTables> cov;
+    int max_chunks = 0, max_L = 0;
+    double *S = nullptr, *yy_train = nullptr, *yy_all = nullptr;
+    double cnt_train = 0, cnt_test = 0;
+    // factor-dependent workspace for the current K
+    int K = 0, NB = 0, KP = 0, nseg = 1, seg_len = 0;
+    double *Astack = nullptr, *R = nullptr, *C = nullptr, *RtR = nullptr, *CCt = nullptr, *Qfull = nullptr, *SC = nullptr;
+    double *stat = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
+    double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
+    int *sweeps = nullptr, *failflag = nullptr;
+    unsigned long long *sweep_total = nullptr;
+    size_t stage_count = 0;
+    int gram_blocks_p = 0, gram_blocks_n = 0, sc_blocks = 0;
+    // sharding
+    int64_t gene_offset = 0;
+    int rank = 0, world = 1;
+    insider_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    // options
+    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0;
+    // profile of the last optimize()
+    std::vector<hipEvent_t> ev_col, ev_row;
+    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+void free_workspace(insider_hip_handle *h)
+{
+    double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->gram_part,
+                       &h->sc_part, &h->lvl_part, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
+                       &h->stage};
+    for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+    if (h->sweeps) (void)hipFree(h->sweeps);
+    if (h->failflag) (void)hipFree(h->failflag);
+    if (h->sweep_total) (void)hipFree(h->sweep_total);
+    h->sweep_total = nullptr;
+    h->sweeps = nullptr;
+    h->failflag = nullptr;
+    h->K = 0;
+}
+
+int ensure_workspace(insider_hip_handle *h, int K)
+{
+    if (K < 1 || K > INSIDER_MAX_K) return fail(INSIDER_ERR_UNSUPPORTED, "K must be in 1..63");
+    if (h->K == K) return INSIDER_OK;
+    free_workspace(h);
+    const int NB = (K + 1 + 15) / 16, KP = 16 * NB, NBLK = NB * (NB + 1) / 2, STAT = NBLK * 256;
+    h->NB = NB;
+    h->KP = KP;
+    // row-side segmentation: enough work items to fill 256 CUs even for few samples
+    int nseg = (int)std::min<int64_t>(std::max<int64_t>(1, cdiv(8192, h->n)), std::max<int64_t>(1, h->ldp / 1024));
+    int seg_len = (int)round_up(cdiv(h->ldp, nseg), CHUNK);
+    nseg = cdiv(h->ldp, seg_len);
+    h->nseg = nseg;
+    h->seg_len = seg_len;
+    h->gram_blocks_p = cdiv(h->p, 256);
+    h->gram_blocks_n = cdiv(h->n, 256);
+    h->sc_blocks = cdiv(h->p, 256);
+    int rc;
+    if ((rc = dmalloc(&h->Astack, (size_t)h->SL * KP))) return rc;
+    if ((rc = dmalloc(&h->R, (size_t)h->n * KP))) return rc;
+    if ((rc = dmalloc(&h->C, (size_t)std::max<int64_t>(h->p, h->ldp) * KP))) return rc;
+    if ((rc = dmalloc(&h->RtR, (size_t)KP * KP))) return rc;
+    if ((rc = dmalloc(&h->CCt, (size_t)KP * KP))) return rc;
+    if ((rc = dmalloc(&h->Qfull, (size_t)h->p * KP))) return rc;
+    if ((rc = dmalloc(&h->SC, (size_t)h->SL * KP))) return rc;
+    if ((rc = dmalloc(&h->stat, (size_t)nseg * h->n * STAT))) return rc;
+    if ((rc = dmalloc(&h->gram_part, (size_t)std::max(h->gram_blocks_p, h->gram_blocks_n) * KP * KP))) return rc;
+    if ((rc = dmalloc(&h->sc_part, (size_t)h->sc_blocks * h->SL * KP))) return rc;
+    if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP)))) return rc;
+    if ((rc = dmalloc(&h->eq, (size_t)h->max_L * (KP * KP + KP)))) return rc;
+    if ((rc = dmalloc(&h->sse_train, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->sse_test, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->b2, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->b1, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->loss_buf, 8))) return rc;
+    h->stage_count = (size_t)std::max<int64_t>(std::max<int64_t>(h->p, h->n), h->SL) * KP;
+    if ((rc = dmalloc(&h->stage, h->stage_count))) return rc;
+    if ((rc = dmalloc(&h->sweeps, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->failflag, 1))) return rc;
+    if ((rc = dmalloc(&h->sweep_total, 1))) return rc;
+    // rows of the padded factor buffers beyond K must stay zero: C rows are gathered with pitch KP and the
+    // pad genes of the transposed layout index rows p..ldp-1
+    HIPCHECK(hipMemsetAsync(h->C, 0, (size_t)std::max<int64_t>(h->p, h->ldp) * KP * sizeof(double), h->stream));
+    HIPCHECK(hipMemsetAsync(h->R, 0, (size_t)h->n * KP * sizeof(double), h->stream));
+    HIPCHECK(hipMemsetAsync(h->failflag, 0, sizeof(int), h->stream));
+    h->K = K;
+    return INSIDER_OK;
+}
+
+// ---- launch helpers (dispatch on NB) -----------------------------------------------------------------------
+#define NB_DISPATCH(NBV, ...)                                                           \
+    switch (NBV) {                                                                      \
+        case 1: { constexpr int NB_ = 1; constexpr int WPB_ = 4; __VA_ARGS__; } break;   \
+        case 2: { constexpr int NB_ = 2; constexpr int WPB_ = 4; __VA_ARGS__; } break;   \
+        case 3: { constexpr int NB_ = 3; constexpr int WPB_ = 2; __VA_ARGS__; } break;   \
+        default: { constexpr int NB_ = 4; constexpr int WPB_ = 1; __VA_ARGS__; } break;  \
+    }
+
+int launch_line_stats(insider_hip_handle *h, const double *vals, const uint8_t *codes, int64_t pitch, int units,
+                      int nseg, int seg_len, const double *F, double *stat)
+{
+    const int64_t items = (int64_t)units * nseg;
+    NB_DISPATCH(h->NB, hipLaunchKernelGGL((k_line_stats<NB_, WPB_>), dim3(cdiv(items, WPB_)), dim3(WPB_ * 64), 0,
+                                           h->stream, vals, codes, pitch, units, nseg, seg_len, F, h->K, stat));
+    KCHECK();
+    return INSIDER_OK;
+}
+
+int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *out)
+{
+    const int nb = cdiv(rows, 256);
+    switch (h->KP) {
+        case 16: hipLaunchKernelGGL((k_gram_partial<16>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
+        case 32: hipLaunchKernelGGL((k_gram_partial<32>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
+        case 48: hipLaunchKernelGGL((k_gram_partial<48>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
+        default: hipLaunchKernelGGL((k_gram_partial<64>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
+    }
+    KCHECK();
+    const int len = h->KP * h->KP;
+    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 256)), dim3(256), 0, h->stream, h->gram_part, nb, len, out);
+    KCHECK();
+    return INSIDER_OK;
+}
+
+// R, R'R and Qfull from the current row factors (src/optimize.cpp:365-369 and the Xty of :222,235 via level sums)
+int phase_R(insider_hip_handle *h)
+{
+    hipLaunchKernelGGL(k_build_R, dim3(cdiv(h->n * h->KP, 256)), dim3(256), 0, h->stream, h->lev, h->lvl_off_d, h->c,
+                       (int)h->n, h->Astack, h->KP, h->R);
+    KCHECK();
+    int rc = launch_gram(h, h->R, h->n, h->RtR);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_qfull, dim3(cdiv(h->p, 256 / h->KP)), dim3(256), 0, h->stream, (const double *)h->S, h->SL,
+                       h->SLP, (const double *)h->Astack, h->KP, (int)h->p, h->Qfull);
+    KCHECK();
+    return INSIDER_OK;
+}
+
+int launch_col(insider_hip_handle *h, int masked, int mode, int checkpoint, const CdParams &cd, bool timed)
+{
+    ColArgs a;
+    a.vals = h->X;
+    a.codes = h->codes;
+    a.pitch = h->ldn;
+    a.p = (int)h->p;
+    a.K = h->K;
+    a.masked = masked;
+    a.R = h->R;
+    a.RtR = h->RtR;
+    a.Qfull = h->Qfull;
+    a.C = h->C;
+    a.yy = masked ? h->yy_train : h->yy_all;
+    a.mode = mode;
+    a.checkpoint = checkpoint;
+    a.cd = cd;
+    a.gene_offset = h->gene_offset;
+    a.sse_train = h->sse_train;
+    a.sse_test = h->sse_test;
+    a.b2 = h->b2;
+    a.b1 = h->b1;
+    a.sweeps = h->sweeps;
+    a.fail = h->failflag;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed && h->profile) {
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        HIPCHECK(hipEventRecord(e0, h->stream));
+    }
+    NB_DISPATCH(h->NB, hipLaunchKernelGGL((k_col_update<NB_, WPB_>), dim3(cdiv(h->p, WPB_)), dim3(WPB_ * 64), 0,
+                                           h->stream, a));
+    KCHECK();
+    if (e0) {
+        HIPCHECK(hipEventRecord(e1, h->stream));
+        h->ev_col.push_back(e0);
+        h->ev_col.push_back(e1);
+    }
+    if (timed && h->profile) {
+        hipLaunchKernelGGL(k_accum_sweeps, dim3(1), dim3(256), 0, h->stream, (const int *)h->sweeps, (int)h->p,
+                           h->sweep_total);
+        KCHECK();
+    }
+    return INSIDER_OK;
+}
+
+int launch_row_stats(insider_hip_handle *h, bool timed)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed && h->profile) {
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        HIPCHECK(hipEventRecord(e0, h->stream));
+    }
+    int rc = launch_line_stats(h, h->Xt, h->codes_t, h->ldp, (int)h->n, h->nseg, h->seg_len, h->C, h->stat);
+    if (rc) return rc;
+    if (e0) {
+        HIPCHECK(hipEventRecord(e1, h->stream));
+        h->ev_row.push_back(e0);
+        h->ev_row.push_back(e1);
+    }
+    return INSIDER_OK;
+}
+
+int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
+{
+    if (h->world <= 1 || !h->allreduce) return INSIDER_OK;
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->allreduce(h->allreduce_user, buf, count) != 0) return fail(INSIDER_ERR_COMM, "all-reduce callback failed");
+    return INSIDER_OK;
+}
+
+// one covariate's row update (optimize_row, src/optimize.cpp:139-198)
+int row_update(insider_hip_handle *h, int i, int masked, double lambda1)
+{
+    const CovTables &ct = h->cov[i];
+    LevelArgs la;
+    la.stat = h->stat;
+    la.nseg = h->nseg;
+    la.n = (int)h->n;
+    la.K = h->K;
+    la.masked = masked;
+    la.lev = h->lev;
+    la.lvl_off = h->lvl_off_d;
+    la.c = h->c;
+    la.cov = i;
+    la.chunk_level = ct.chunk_level;
+    la.chunk_begin = ct.chunk_begin;
+    la.chunk_end = ct.chunk_end;
+    la.members = h->members_all + (size_t)i * h->n;
+    la.nchunks = ct.nchunks;
+    la.Astack = h->Astack;
+    la.part = h->lvl_part;
+    LevelReduceArgs ra;
+    ra.part = h->lvl_part;
+    ra.lvl_chunk_ptr = ct.lvl_chunk_ptr;
+    ra.lvl_count = h->lvl_count_all + h->lvl_off[i];
+    ra.L = ct.L;
+    ra.K = h->K;
+    ra.CCt = h->CCt;
+    ra.SC = h->SC;
+    ra.sc_off = h->lvl_off[i];
+    ra.eq = h->eq;
+    NB_DISPATCH(h->NB, {
+        (void)WPB_;
+        hipLaunchKernelGGL((k_level_partial<NB_>), dim3(ct.nchunks), dim3(64), 0, h->stream, la);
+        hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(ct.L), dim3(64), 0, h->stream, ra);
+    });
+    KCHECK();
+    int rc = do_allreduce(h, h->eq, (int64_t)ct.L * (h->KP * h->KP + h->KP));
+    if (rc) return rc;
+    NB_DISPATCH(h->NB, {
+        (void)WPB_;
+        hipLaunchKernelGGL((k_level_solve<NB_>), dim3(ct.L), dim3(64), 0, h->stream, h->eq,
+                           h->lvl_count_all + h->lvl_off[i], ct.L, h->K, lambda1,
+                           h->Astack + (size_t)h->lvl_off[i] * h->KP, h->failflag);
+    });
+    KCHECK();
+    return INSIDER_OK;
+}
+
+struct LossOut {
+    double sum_residual, train_rmse, test_rmse, row_reg_half, col_reg_half, l1_reg, loss;
+};
+
+// evaluate() + compute_loss() (src/utils.cpp:56-102) from the per-gene statistics of the last column pass
+int loss_checkpoint(insider_hip_handle *h, int tuning, double lambda1, double lambda2, double alpha, LossOut *o)
+{
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, h->stream, h->sse_train, h->sse_test, h->b2, h->b1,
+                       (int)h->p, h->Astack, h->SL, h->K, h->KP, h->loss_buf);
+    KCHECK();
+    // layout: [0]=sse_train [1]=sse_test [2]=sum c^2 [3]=sum |c| [4]=cnt_train [5]=cnt_test | [6]=sum a^2 (replicated)
+    double cnt[2] = {tuning == 1 ? h->cnt_train : (double)h->n * (double)h->p, h->cnt_test};
+    HIPCHECK(hipMemcpyAsync(h->loss_buf + 4, cnt, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = do_allreduce(h, h->loss_buf, 6);
+    if (rc) return rc;
+    double v[8];
+    HIPCHECK(hipMemcpyAsync(v, h->loss_buf, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    o->sum_residual = v[0];
+    o->train_rmse = std::sqrt(v[0] / v[4]);                                                   // :63,66
+    o->test_rmse = (tuning == 1 && v[5] > 0) ? std::sqrt(v[1] / v[5]) : std::numeric_limits<double>::quiet_NaN();
+    const double nfA = std::sqrt(v[6]), nfC = std::sqrt(v[2]);
+    o->row_reg_half = lambda1 * nfA * nfA / 2;                                                // :83-86 (all A_i share lambda1)
+    o->col_reg_half = lambda2 * (1 - alpha) * nfC * nfC / 2;                                  // :88
+    o->l1_reg = lambda2 * alpha * v[3];                                                       // :91
+    o->loss = o->sum_residual / 2 + o->row_reg_half + o->col_reg_half + o->l1_reg;            // :93
+    return INSIDER_OK;
+}
+
+int check_fail_flag(insider_hip_handle *h)
+{
+    int f = 0;
+    HIPCHECK(hipMemcpyAsync(&f, h->failflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (f) {
+        HIPCHECK(hipMemsetAsync(h->failflag, 0, sizeof(int), h->stream));
+        return fail(INSIDER_ERR_SOLVE, "a ridge normal-equation system was not positive definite");
+    }
+    return INSIDER_OK;
+}
+
+void clear_events(insider_hip_handle *h)
+{
+    for (auto e : h->ev_col) (void)hipEventDestroy(e);
+    for (auto e : h->ev_row) (void)hipEventDestroy(e);
+    h->ev_col.clear();
+    h->ev_row.clear();
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char *insider_hip_version(void) { return "insider_hip 0.1.0 (gfx950)"; }
+
+const char *insider_hip_last_error(void) { return g_err.c_str(); }
+
+int insider_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void insider_hip_destroy(insider_hip_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    clear_events(h);
+    free_workspace(h);
+    void *ptrs[] = {h->X, h->Xt, h->codes, h->codes_t, h->lev, h->lvl_off_d, h->members_all, h->lvl_ptr_all,
+                    h->lvl_count_all, h->S, h->yy_train, h->yy_all};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (auto &ct : h->cov) {
+        if (ct.chunk_level) (void)hipFree(ct.chunk_level);
+        if (ct.chunk_begin) (void)hipFree(ct.chunk_begin);
+        if (ct.chunk_end) (void)hipFree(ct.chunk_end);
+        if (ct.lvl_chunk_ptr) (void)hipFree(ct.lvl_chunk_ptr);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *levels, int c, const int32_t *n_levels,
+                       const uint8_t *M_train, const uint8_t *M_test, int device, insider_hip_handle **out)
+{
+    if (!out) return fail(INSIDER_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!X || !levels || !n_levels || !M_train || !M_test) return fail(INSIDER_ERR_ARG, "null input");
+    if (n < 1 || p < 1 || c < 1) return fail(INSIDER_ERR_ARG, "n, p, c must be positive");
+    if (n > (1 << 30) || p > (1 << 30)) return fail(INSIDER_ERR_ARG, "dimension too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(INSIDER_ERR_NO_DEVICE, "no HIP device visible: libinsider_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(INSIDER_ERR_ARG, "bad device ordinal");
+    // level ids must be exactly 1..L_i (src/optimize.cpp:175,286)
+    for (int i = 0; i < c; ++i) {
+        if (n_levels[i] < 1) return fail(INSIDER_ERR_ARG, "n_levels must be positive");
+        for (int64_t r = 0; r < n; ++r) {
+            const int32_t l = levels[r + (size_t)i * n];
+            if (l < 1 || l > n_levels[i]) return fail(INSIDER_ERR_ARG, "level ids must be within 1..L_i");
+        }
+    }
+    HIPCHECK(hipSetDevice(device));
+    insider_hip_handle *h = new insider_hip_handle();
+    h->device = device;
+    h->n = n;
+    h->p = p;
+    h->c = c;
+    h->ldn = round_up(n, CHUNK);
+    h->ldp = round_up(p, CHUNK);
+    h->n_levels.assign(n_levels, n_levels + c);
+    h->lvl_off.assign(c + 1, 0);
+    for (int i = 0; i < c; ++i) h->lvl_off[i + 1] = h->lvl_off[i] + n_levels[i];
+    h->SL = h->lvl_off[c];
+    h->SLP = (int)round_up(h->SL, 2);
+    int rc = INSIDER_OK;
+#define CR(x) do { rc = (x); if (rc) { insider_hip_destroy(h); return rc; } } while (0)
+#define CH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { insider_hip_destroy(h); \
+        return fail(e_ == hipErrorOutOfMemory ? INSIDER_ERR_ALLOC : INSIDER_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+    CH(hipStreamCreate(&h->stream));
+    // ---- X (gene-major lines of pitch ldn) and mask codes -------------------------------------------------
+    CR(dmalloc(&h->X, (size_t)p * h->ldn));
+    CR(dmalloc(&h->codes, (size_t)p * h->ldn));
+    CH(hipMemsetAsync(h->X, 0, (size_t)p * h->ldn * sizeof(double), h->stream));
+    CH(hipMemcpy2DAsync(h->X, h->ldn * sizeof(double), X, n * sizeof(double), n * sizeof(double), p,
+                        hipMemcpyHostToDevice, h->stream));
+    {
+        uint8_t *mtr = nullptr, *mte = nullptr;
+        CR(dmalloc(&mtr, (size_t)n * p));
+        CR(dmalloc(&mte, (size_t)n * p));
+        CH(hipMemcpyAsync(mtr, M_train, (size_t)n * p, hipMemcpyHostToDevice, h->stream));
+        CH(hipMemcpyAsync(mte, M_test, (size_t)n * p, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_make_codes, dim3(cdiv(p * h->ldn, 256)), dim3(256), 0, h->stream, mtr, mte, n, p, h->ldn,
+                           h->codes);
+        CH(hipGetLastError());
+        CH(hipStreamSynchronize(h->stream));
+        (void)hipFree(mtr);
+        (void)hipFree(mte);
+    }
+    // ---- transposed copies for the row-side pass (sample-major lines of pitch ldp) --------------------------
+    CR(dmalloc(&h->Xt, (size_t)n * h->ldp));
+    CR(dmalloc(&h->codes_t, (size_t)n * h->ldp));
+    CH(hipMemsetAsync(h->Xt, 0, (size_t)n * h->ldp * sizeof(double), h->stream));
+    CH(hipMemsetAsync(h->codes_t, CODE_TRAIN, (size_t)n * h->ldp, h->stream));
+    {
+        dim3 grid(cdiv(n, 32), cdiv(p, 32));   // input: p lines (rows) x n columns
+        hipLaunchKernelGGL((k_transpose<double>), grid, dim3(256), 0, h->stream, (const double *)h->X, p, n, h->ldn,
+                           h->Xt, h->ldp);
+        hipLaunchKernelGGL((k_transpose<uint8_t>), grid, dim3(256), 0, h->stream, (const uint8_t *)h->codes, p, n,
+                           h->ldn, h->codes_t, h->ldp);
+        CH(hipGetLastError());
+    }
+    // ---- level tables ------------------------------------------------------------------------------------------
+    {
+        std::vector<int> lev0((size_t)c * n), members((size_t)c * n), lvl_ptr((size_t)h->SL + c), lvl_count(h->SL);
+        h->cov.resize(c);
+        for (int i = 0; i < c; ++i) {
+            const int L = n_levels[i];
+            std::vector<int> cnt(L, 0);
+            for (int64_t r = 0; r < n; ++r) {
+                const int l = levels[r + (size_t)i * n] - 1;
+                lev0[(size_t)i * n + r] = l;
+                cnt[l]++;
+            }
+            int *ptr = lvl_ptr.data() + h->lvl_off[i] + i;
+            ptr[0] = 0;
+            for (int l = 0; l < L; ++l) { ptr[l + 1] = ptr[l] + cnt[l]; lvl_count[h->lvl_off[i] + l] = cnt[l]; }
+            std::vector<int> fill(ptr, ptr + L);
+            for (int64_t r = 0; r < n; ++r) members[(size_t)i * n + fill[lev0[(size_t)i * n + r]]++] = (int)r;
+            // chunk tables for the two-stage level reduction
+            std::vector<int> ch_level, ch_begin, ch_end, lcp(L + 1, 0);
+            for (int l = 0; l < L; ++l) {
+                lcp[l] = (int)ch_level.size();
+                for (int b = ptr[l]; b < ptr[l + 1]; b += LEVEL_CHUNK) {
+                    ch_level.push_back(l);
+                    ch_begin.push_back(b);
+                    ch_end.push_back(std::min(b + LEVEL_CHUNK, ptr[l + 1]));
+                }
+            }
+            lcp[L] = (int)ch_level.size();
+            CovTables &ct = h->cov[i];
+            ct.L = L;
+            ct.nchunks = (int)ch_level.size();
+            h->max_chunks = std::max(h->max_chunks, ct.nchunks);
+            h->max_L = std::max(h->max_L, L);
+            CR(dmalloc(&ct.chunk_level, ch_level.size()));
+            CR(dmalloc(&ct.chunk_begin, ch_begin.size()));
+            CR(dmalloc(&ct.chunk_end, ch_end.size()));
+            CR(dmalloc(&ct.lvl_chunk_ptr, lcp.size()));
+            CH(hipMemcpy(ct.chunk_level, ch_level.data(), ch_level.size() * sizeof(int), hipMemcpyHostToDevice));
+            CH(hipMemcpy(ct.chunk_begin, ch_begin.data(), ch_begin.size() * sizeof(int), hipMemcpyHostToDevice));
+            CH(hipMemcpy(ct.chunk_end, ch_end.data(), ch_end.size() * sizeof(int), hipMemcpyHostToDevice));
+            CH(hipMemcpy(ct.lvl_chunk_ptr, lcp.data(), lcp.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        CR(dmalloc(&h->lev, lev0.size()));
+        CR(dmalloc(&h->members_all, members.size()));
+        CR(dmalloc(&h->lvl_ptr_all, lvl_ptr.size()));
+        CR(dmalloc(&h->lvl_count_all, lvl_count.size()));
+        CR(dmalloc(&h->lvl_off_d, h->lvl_off.size()));
+        CH(hipMemcpy(h->lev, lev0.data(), lev0.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->members_all, members.data(), members.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->lvl_ptr_all, lvl_ptr.data(), lvl_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->lvl_count_all, lvl_count.data(), lvl_count.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->lvl_off_d, h->lvl_off.data(), h->lvl_off.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // ---- factor-independent statistics -----------------------------------------------------------------------------
+    CR(dmalloc(&h->S, (size_t)p * h->SLP));
+    CR(dmalloc(&h->yy_train, (size_t)p));
+    CR(dmalloc(&h->yy_all, (size_t)p));
+    CH(hipMemsetAsync(h->S, 0, (size_t)p * h->SLP * sizeof(double), h->stream));
+    {
+        unsigned long long *cnt = nullptr;
+        CR(dmalloc(&cnt, 2));
+        CH(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(k_line_sumsq, dim3(cdiv(p, 4)), dim3(256), 0, h->stream, (const double *)h->X,
+                           (const uint8_t *)h->codes, h->ldn, (int)n, (int)p, h->yy_train, h->yy_all, cnt);
+        hipLaunchKernelGGL(k_level_sums, dim3(cdiv(p * h->SL, 256)), dim3(256), 0, h->stream, (const double *)h->X,
+                           h->ldn, (int)p, (const int *)h->members_all, (const int *)h->lvl_ptr_all,
+                           (const int *)h->lvl_off_d, c, (int)n, h->SL, h->SLP, h->S);
+        CH(hipGetLastError());
+        unsigned long long hc[2];
+        CH(hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
+        CH(hipStreamSynchronize(h->stream));
+        (void)hipFree(cnt);
+        // pad elements of each line are coded "train" with x = 0: remove them from the count
+        h->cnt_train = (double)hc[0];
+        h->cnt_test = (double)hc[1];
+    }
+#undef CR
+#undef CH
+    *out = h;
+    return INSIDER_OK;
+}
+
+int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, int world, insider_allreduce_fn fn,
+                          void *user)
+{
+    if (!h || world < 1 || rank < 0 || rank >= world || gene_offset < 0) return fail(INSIDER_ERR_ARG, "bad shard");
+    if (world > 1 && !fn) return fail(INSIDER_ERR_ARG, "world > 1 needs an all-reduce callback");
+    h->gene_offset = gene_offset;
+    h->rank = rank;
+    h->world = world;
+    h->allreduce = fn;
+    h->allreduce_user = user;
+    return INSIDER_OK;
+}
+
+int insider_hip_set_option(insider_hip_handle *h, const char *name, double value)
+{
+    if (!h || !name) return fail(INSIDER_ERR_ARG, "null");
+    const std::string s(name);
+    if (s == "max_sweeps") h->max_sweeps = value < 1 ? 1 : (int)value;
+    else if (s == "order_mode") h->order_mode = (int)value;
+    else if (s == "profile") h->profile = (int)value;
+    else if (s == "verbose") h->verbose = (int)value;
+    else return fail(INSIDER_ERR_ARG, "unknown option " + s);
+    return INSIDER_OK;
+}
+
+int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K, double lambda1,
+                         double lambda2, double alpha, int tuning, double global_tol, double sub_tol, uint32_t max_iter,
+                         uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss, double *traj,
+                         int traj_cap, int *out_traj_rows, int *out_iters)
+{
+    if (!h || !A || !C) return fail(INSIDER_ERR_ARG, "null argument");
+    if (tuning != 0 && tuning != 1)   // the reference prints and exit(1)s here (src/optimize.cpp:249-251)
+        return fail(INSIDER_ERR_ARG, "Parameter tuning should be either 0 or 1!");
+    if (inc_continuous != 0 && inc_continuous != 1)   // src/optimize.cpp:270-272
+        return fail(INSIDER_ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.");
+    if (inc_continuous == 1) return fail(INSIDER_ERR_UNSUPPORTED, "continuous covariates are not supported yet");
+    for (int i = 0; i < h->c; ++i) if (!A[i]) return fail(INSIDER_ERR_ARG, "null row factor");
+    HIPCHECK(hipSetDevice(h->device));
+    int rc = ensure_workspace(h, K);
+    if (rc) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    clear_events(h);
+    const int KP = h->KP;
+    const int masked = tuning == 1;
+    // ---- upload the inits (the reference aliases R's memory, src/optimize.cpp:283-284) --------------------------
+    for (int i = 0; i < h->c; ++i) {
+        const int L = h->n_levels[i];
+        HIPCHECK(hipMemcpyAsync(h->stage, A[i], (size_t)L * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_pack_A, dim3(cdiv(L * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, L, K, KP,
+                           h->Astack + (size_t)h->lvl_off[i] * KP);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));   // stage is reused
+    }
+    HIPCHECK(hipMemcpyAsync(h->stage, C, (size_t)h->p * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(h->p * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, h->p, K,
+                       KP, h->C);
+    KCHECK();
+
+    CdParams cd;
+    cd.lambda = lambda2;
+    cd.alpha = alpha;
+    cd.tol = sub_tol;
+    cd.seed = seed;
+    cd.iter = 0;
+    cd.max_sweeps = h->max_sweeps;
+    cd.order_mode = h->order_mode;
+    const int solve_mode = alpha == 0.0 ? COL_RIDGE : COL_CD;
+
+    // ---- fit of the initial values (src/optimize.cpp:320-323) ----------------------------------------------------
+    LossOut lo;
+    if ((rc = phase_R(h))) return rc;
+    if ((rc = launch_col(h, masked, COL_EVAL, 1, cd, false))) return rc;
+    if ((rc = loss_checkpoint(h, tuning, lambda1, lambda2, alpha, &lo))) return rc;
+    double loss = lo.loss, pre_loss, decay = 1.0;
+    double train_rmse = lo.train_rmse, test_rmse = lo.test_rmse;
+    int trows = 0;
+    auto put_traj = [&](double it, double delta, double dec) {
+        if (traj && trows < traj_cap) {
+            double *t = traj + (size_t)trows * INSIDER_TRAJ_STRIDE;
+            t[0] = it; t[1] = lo.train_rmse; t[2] = lo.test_rmse; t[3] = lo.sum_residual / 2; t[4] = lo.row_reg_half;
+            t[5] = lo.col_reg_half; t[6] = lo.l1_reg; t[7] = lo.loss; t[8] = delta; t[9] = dec;
+            ++trows;
+        }
+    };
+    put_traj(-1, std::numeric_limits<double>::quiet_NaN(), decay);
+
+    uint32_t iter = 0;
+    unsigned long long sweeps_total = 0;
+    HIPCHECK(hipMemsetAsync(h->sweep_total, 0, sizeof(unsigned long long), h->stream));
+    while (iter <= max_iter) {                                                                  // :325
+        if (h->verbose && iter % 10 == 0) printf("Iteration %u ---------------------------------\n", iter);
+        // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
+        if ((rc = launch_gram(h, h->C, h->p, h->CCt))) return rc;                               // :332
+        {
+            const int LT = 256 / KP;
+            dim3 grid(h->sc_blocks, cdiv(h->SL, LT));
+            hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream, (const double *)h->S, h->SL, h->SLP,
+                               (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
+            KCHECK();
+            const int len = h->SL * KP;
+            hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 256)), dim3(256), 0, h->stream, (const double *)h->sc_part,
+                               h->sc_blocks, len, h->SC);
+            KCHECK();
+        }
+        if (masked) if ((rc = launch_row_stats(h, true))) return rc;
+        for (int i = 0; i < h->c; ++i)
+            if ((rc = row_update(h, i, masked, lambda1))) return rc;                            // :339
+        // ---- column step (:365-378) -------------------------------------------------------------------------------
+        if ((rc = phase_R(h))) return rc;
+        const int checkpoint = iter % 10 == 0;
+        cd.tol = sub_tol * decay;                                                               // :376
+        cd.iter = iter;
+        if ((rc = launch_col(h, masked, solve_mode, checkpoint, cd, true))) return rc;
+        if (checkpoint) {                                                                       // :381-408
+            pre_loss = loss;
+            if ((rc = loss_checkpoint(h, tuning, lambda1, lambda2, alpha, &lo))) return rc;
+            if ((rc = check_fail_flag(h))) return rc;
+            loss = lo.loss;
+            train_rmse = lo.train_rmse;
+            test_rmse = lo.test_rmse;
+            const double delta_loss = pre_loss - loss;
+            if (delta_loss / 1000 <= 1e-6) decay = 1e-6;                                        // :389-403
+            else if (delta_loss / 1000 <= 1e-5) decay = 1e-5;
+            else if (delta_loss / 1000 <= 1e-4) decay = 1e-4;
+            else if (delta_loss / 1000 <= 1e-3) decay = 1e-3;
+            else if (delta_loss / 1000 <= 1e-2) decay = 1e-2;
+            else if (delta_loss / 1000 <= 1e-1) decay = 1e-1;
+            else decay = 1.0;
+            put_traj(iter, delta_loss, decay);
+            if (h->verbose) {
+                printf("insider iter %u: train rmse = %.12g\n", iter, train_rmse);
+                if (tuning == 1) printf("insider iter %u: test rmse = %.12g\n", iter, test_rmse);
+                printf("total_residual\t%.12g;\nrow_reg_loss:\t%.12g;\ncol_reg_loss:\t%.12g;\nl1_reg_loss:\t%.12g.\n",
+                       lo.sum_residual / 2, lo.row_reg_half, lo.col_reg_half, lo.l1_reg);
+                printf("Delta loss for iter %u:%.12g\n", iter, delta_loss);
+            }
+            if ((pre_loss - loss) / pre_loss < global_tol) break;                               // :405-407
+        }
+        ++iter;
+    }
+    // ---- results back (the reference returns copies AND has mutated the inputs in place, :413-421) ---------------
+    for (int i = 0; i < h->c; ++i) {
+        const int L = h->n_levels[i];
+        hipLaunchKernelGGL(k_unpack_A, dim3(cdiv(L * K, 256)), dim3(256), 0, h->stream,
+                           (const double *)(h->Astack + (size_t)h->lvl_off[i] * KP), L, K, KP, h->stage);
+        KCHECK();
+        HIPCHECK(hipMemcpyAsync(A[i], h->stage, (size_t)L * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    hipLaunchKernelGGL(k_unpack_rows, dim3(cdiv(h->p * K, 256)), dim3(256), 0, h->stream, (const double *)h->C, h->p, K,
+                       KP, h->stage);
+    KCHECK();
+    HIPCHECK(hipMemcpyAsync(C, h->stage, (size_t)h->p * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if ((rc = check_fail_flag(h))) return rc;
+    HIPCHECK(hipMemcpy(&sweeps_total, h->sweep_total, sizeof(sweeps_total), hipMemcpyDeviceToHost));
+    if (out_train_rmse) *out_train_rmse = train_rmse;
+    if (out_test_rmse) *out_test_rmse = test_rmse;
+    if (out_loss) *out_loss = loss;
+    if (out_traj_rows) *out_traj_rows = trows;
+    if (out_iters) *out_iters = (int)iter;
+    // ---- profile -------------------------------------------------------------------------------------------------------
+    const auto t_end = std::chrono::steady_clock::now();
+    for (double &v : h->prof) v = 0;
+    auto sum_events = [&](std::vector<hipEvent_t> &ev, double *launches, double *ms) {
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) { *ms += t; *launches += 1; }
+        }
+    };
+    sum_events(h->ev_col, &h->prof[0], &h->prof[1]);
+    sum_events(h->ev_row, &h->prof[2], &h->prof[3]);
+    h->prof[4] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+    h->prof[5] = (double)std::min<uint64_t>((uint64_t)iter + 1, (uint64_t)max_iter + 1);
+    h->prof[6] = (double)sweeps_total;
+    clear_events(h);
+    return INSIDER_OK;
+}
+
+int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *const *A, double *C,
+                                 const int32_t *levels, int c, const int32_t *n_levels, const uint8_t *M_train,
+                                 const uint8_t *M_test, int inc_continuous, int K, double lambda1, double lambda2,
+                                 double alpha, int tuning, double global_tol, double sub_tol, uint32_t max_iter,
+                                 uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss)
+{
+    insider_hip_handle *h = nullptr;
+    int rc = insider_hip_create(X, n, p, levels, c, n_levels, M_train, M_test, 0, &h);
+    if (rc) return rc;
+    rc = insider_hip_optimize(h, A, C, inc_continuous, K, lambda1, lambda2, alpha, tuning, global_tol, sub_tol, max_iter,
+                              seed, out_train_rmse, out_test_rmse, out_loss, nullptr, 0, nullptr, nullptr);
+    const std::string keep = g_err;
+    insider_hip_destroy(h);
+    g_err = keep;
+    return rc;
+}
+
+int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob, double lambda,
+                          double alpha, double tol, uint64_t seed, uint32_t unit0, uint32_t iter, int order_mode,
+                          int max_sweeps, int device, double *beta_out, int32_t *sweeps_out)
+{
+    if (!XtX || !Xty || !wstart || !beta_out) return fail(INSIDER_ERR_ARG, "null argument");
+    if (K < 1 || K > 64 || nprob < 0) return fail(INSIDER_ERR_ARG, "K must be in 1..64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(INSIDER_ERR_NO_DEVICE, "no HIP device visible: libinsider_hip has no CPU fallback");
+    if (nprob == 0) return INSIDER_OK;
+    HIPCHECK(hipSetDevice(device));
+    double *dG = nullptr, *dq = nullptr, *dw = nullptr, *db = nullptr;
+    int *ds = nullptr;
+    int rc;
+    if ((rc = dmalloc(&dG, (size_t)nprob * K * K)) || (rc = dmalloc(&dq, (size_t)nprob * K)) ||
+        (rc = dmalloc(&dw, (size_t)nprob * K)) || (rc = dmalloc(&db, (size_t)nprob * K)) ||
+        (rc = dmalloc(&ds, (size_t)nprob)))
+        return rc;
+    HIPCHECK(hipMemcpy(dG, XtX, (size_t)nprob * K * K * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dq, Xty, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dw, wstart, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
+    CdParams cd;
+    cd.lambda = lambda;
+    cd.alpha = alpha;
+    cd.tol = tol;
+    cd.seed = seed;
+    cd.iter = iter;
+    cd.max_sweeps = max_sweeps < 1 ? 1 : max_sweeps;
+    cd.order_mode = order_mode;
+    hipLaunchKernelGGL((k_cd_batch<1>), dim3((unsigned)nprob), dim3(64), 0, 0, (const double *)dG, (const double *)dq,
+                       (const double *)dw, K, nprob, cd, unit0, db, ds);
+    KCHECK();
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(beta_out, db, (size_t)nprob * K * sizeof(double), hipMemcpyDeviceToHost));
+    if (sweeps_out) HIPCHECK(hipMemcpy(sweeps_out, ds, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dG); (void)hipFree(dq); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(ds);
+    return INSIDER_OK;
+}
+
+static int masked_gram_common(insider_hip_handle *h, bool cols, const double *Fhost, int K, double *G_out, double *q_out)
+{
+    if (!h || !Fhost || !G_out || !q_out) return fail(INSIDER_ERR_ARG, "null argument");
+    HIPCHECK(hipSetDevice(h->device));
+    int rc = ensure_workspace(h, K);
+    if (rc) return rc;
+    const int KP = h->KP;
+    const int64_t units = cols ? h->p : h->n, flen = cols ? h->n : h->p;
+    double *F = cols ? h->R : h->C, *full = cols ? h->RtR : h->CCt;
+    // host factor: cols -> R is n x K column-major; rows -> C is K x p column-major (= p rows of K)
+    HIPCHECK(hipMemcpy(h->stage, Fhost, (size_t)flen * K * sizeof(double), hipMemcpyHostToDevice));
+    if (cols) hipLaunchKernelGGL(k_pack_A, dim3(cdiv(flen * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage,
+                                 (int)flen, K, KP, F);
+    else hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(flen * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage,
+                            flen, K, KP, F);
+    KCHECK();
+    if ((rc = launch_gram(h, F, flen, full))) return rc;
+    double *stat = nullptr, *qf = nullptr, *Gd = nullptr, *qd = nullptr;
+    const int NBLK = h->NB * (h->NB + 1) / 2, STAT = NBLK * 256;
+    const int nseg = cols ? 1 : h->nseg, seg_len = cols ? (int)h->ldn : h->seg_len;
+    if ((rc = dmalloc(&stat, (size_t)nseg * units * STAT)) || (rc = dmalloc(&qf, (size_t)units * KP)) ||
+        (rc = dmalloc(&Gd, (size_t)units * K * K)) || (rc = dmalloc(&qd, (size_t)units * K)))
+        return rc;
+    const double *vals = cols ? h->X : h->Xt;
+    const uint8_t *codes = cols ? h->codes : h->codes_t;
+    const int64_t pitch = cols ? h->ldn : h->ldp;
+    if ((rc = launch_line_stats(h, vals, codes, pitch, (int)units, nseg, seg_len, F, stat))) return rc;
+    hipLaunchKernelGGL(k_line_dense_xty, dim3((unsigned)units), dim3(64), 0, h->stream, vals, pitch, (int)flen,
+                       (const double *)F, K, KP, qf);
+    KCHECK();
+    NB_DISPATCH(h->NB, {
+        (void)WPB_;
+        hipLaunchKernelGGL((k_stats_to_dense<NB_>), dim3((unsigned)units), dim3(64), 0, h->stream, (const double *)stat,
+                           nseg, (int)units, K, (const double *)full, (const double *)qf, Gd, qd);
+    });
+    KCHECK();
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpy(G_out, Gd, (size_t)units * K * K * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(q_out, qd, (size_t)units * K * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(stat); (void)hipFree(qf); (void)hipFree(Gd); (void)hipFree(qd);
+    // the pad rows of C (genes p..ldp-1) were not touched; R/C now hold the caller's factor
+    return INSIDER_OK;
+}
+
+int insider_hip_masked_gram_cols(insider_hip_handle *h, const double *R, int K, double *G_out, double *q_out)
+{
+    return masked_gram_common(h, true, R, K, G_out, q_out);
+}
+
+int insider_hip_masked_gram_rows(insider_hip_handle *h, const double *C, int K, double *H_out, double *b_out)
+{
+    return masked_gram_common(h, false, C, K, H_out, b_out);
+}
+
+int insider_hip_get_profile(insider_hip_handle *h, double *out8)
+{
+    if (!h || !out8) return fail(INSIDER_ERR_ARG, "null");
+    for (int i = 0; i < 8; ++i) out8[i] = h->prof[i];
+    return INSIDER_OK;
+}
+
+}  // extern "C"

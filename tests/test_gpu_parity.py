@@ -1,0 +1,290 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp64): statistics rel 1e-11; one outer iteration rel 1e-9 on the factors;
+31 iterations rel 1e-6 on the factors, 1e-9 on the loss trajectory.  The GPU path sums in a different order
+(complement statistics on MFMA, level sums) so bitwise equality is not expected.
+"""
+import numpy as np
+import pytest
+
+from insider_amd import _lib, api, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def _rand_factors(w, seed, scale=0.5):
+    rng = np.random.default_rng(seed)
+    A = [np.asfortranarray(rng.standard_normal(a.shape) * scale) for a in w.A0]
+    C = np.asfortranarray(rng.standard_normal(w.C0.shape) * scale)
+    return A, C
+
+
+def _cp(w):
+    """Fresh copies of the inits: optimize() updates float64 Fortran arrays in place, like the reference."""
+    return [a.copy(order="F") for a in w.A0], w.C0.copy(order="F")
+
+
+def _R(w, A):
+    return sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X box")
+
+
+# K + 1 <= 16 -> one MFMA block, <= 32 -> 2x2 blocks, ... : cover every block geometry and its edges
+@pytest.mark.parametrize("K", [1, 4, 15, 16, 30, 31, 32, 47, 48, 63])
+def test_masked_gram_cols_and_rows(oracle, K):
+    w = workloads.small(n=150, p=70, level_counts=(6, 5), K=K, f=0.15, seed=K, with_na=True)
+    A, C = _rand_factors(w, K + 1)
+    R = _R(w, A)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    G, q = ds.masked_gram_cols(R)
+    H, b = ds.masked_gram_rows(C)
+    ds.close()
+    for j in range(w.p):
+        XtX, Xty = oracle.masked_gram_col(w.X[:, j], w.M_train[:, j], R)
+        assert relerr(G[j], XtX) < 1e-11 and relerr(q[j], Xty) < 1e-11, j
+    for r in range(w.n):
+        XtX, Xty = oracle.masked_gram_row(w.X, w.M_train, r, C)
+        assert relerr(H[r], XtX) < 1e-11 and relerr(b[r], Xty) < 1e-11, r
+
+
+def test_masked_gram_edge_masks(oracle):
+    # empty held-out set, everything held out, ragged sizes (n, p not multiples of the 128-element chunk)
+    w = workloads.small(n=131, p=37, level_counts=(4, 3), K=5, f=0.2, seed=3)
+    w.M_train[5, :] = 0          # sample with (nearly) everything held out
+    w.M_train[6, :] = 1
+    w.M_train[:, 0] = 1          # gene with nothing held out
+    w.M_train[:, 1] = 0          # gene with everything held out
+    A, C = _rand_factors(w, 9)
+    R = _R(w, A)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    G, q = ds.masked_gram_cols(R)
+    H, b = ds.masked_gram_rows(C)
+    ds.close()
+    for j in (0, 1, 2, 36):
+        XtX, Xty = oracle.masked_gram_col(w.X[:, j], w.M_train[:, j], R)
+        np.testing.assert_allclose(G[j], XtX, atol=1e-10)
+        np.testing.assert_allclose(q[j], Xty, atol=1e-10)
+    assert np.abs(G[1]).max() < 1e-10 and np.abs(q[1]).max() < 1e-10
+    for r in (5, 6, 130):
+        XtX, Xty = oracle.masked_gram_row(w.X, w.M_train, r, C)
+        np.testing.assert_allclose(H[r], XtX, atol=1e-10)
+        np.testing.assert_allclose(b[r], Xty, atol=1e-10)
+
+
+def test_masked_gram_long_lines_exercise_ring_drain(oracle):
+    # > 256 held-out entries per line forces mid-line drains of the LDS ring and the segment split on the row side
+    w = workloads.small(n=3000, p=20, level_counts=(10, 3), K=7, f=0.5, seed=4)
+    A, C = _rand_factors(w, 2)
+    R = _R(w, A)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    G, q = ds.masked_gram_cols(R)
+    ds.close()
+    for j in range(w.p):
+        XtX, Xty = oracle.masked_gram_col(w.X[:, j], w.M_train[:, j], R)
+        assert relerr(G[j], XtX) < 1e-11 and relerr(q[j], Xty) < 1e-11
+    w2 = workloads.small(n=12, p=9000, level_counts=(3, 2), K=7, f=0.4, seed=5)
+    A2, C2 = _rand_factors(w2, 3)
+    ds = api.InsiderData(w2.X, w2.levels, w2.M_train, w2.M_test)
+    H, b = ds.masked_gram_rows(C2)
+    ds.close()
+    for r in range(w2.n):
+        XtX, Xty = oracle.masked_gram_row(w2.X, w2.M_train, r, C2)
+        assert relerr(H[r], XtX) < 1e-11 and relerr(b[r], Xty) < 1e-11
+
+
+@pytest.mark.parametrize("K,lam,alpha,tol", [(1, 1.0, 0.5, 1e-12), (5, 2.0, 0.4, 1e-5), (20, 5.0, 0.2, 1e-8),
+                                              (30, 10.0, 0.5, 1e-11), (64, 3.0, 0.3, 1e-7)])
+def test_strong_cd_matches_oracle(oracle, K, lam, alpha, tol):
+    rng = np.random.default_rng(K)
+    B, m = 48, 200
+    Gs, qs, ws, Xs, ys = [], [], [], [], []
+    for b in range(B):
+        X = rng.standard_normal((m, K))
+        bt = rng.standard_normal(K) * (rng.random(K) < 0.6)
+        y = X @ bt + 0.5 * rng.standard_normal(m)
+        Xs.append(X); ys.append(y); Gs.append(X.T @ X); qs.append(X.T @ y); ws.append(rng.standard_normal(K) * 0.1)
+    for mode in (0, 1):
+        beta, sw = api.strong_coordinate_descent(None, None, np.array(ws), lam, alpha, np.array(Gs), np.array(qs),
+                                                 tol=tol, seed=99, unit=1000, it=7, order_mode=mode,
+                                                 return_sweeps=True)
+        same_sweeps = 0
+        for b in range(B):
+            ob, osw = oracle.strong_cd(Xs[b], ys[b], ws[b], lam, alpha, Gs[b], qs[b], tol=tol, seed=99, unit=1000 + b,
+                                       it=7, order_mode=mode)
+            same_sweeps += int(osw == sw[b])
+            # identical sweep order; the stopping rule differences the loss differently (exact increments on the
+            # GPU, two large numbers in the reference), so allow one sweep of slack at loose tolerances
+            assert abs(osw - sw[b]) <= 1
+            assert np.max(np.abs(ob - beta[b])) < max(50 * np.sqrt(tol), 1e-9) if osw != sw[b] else \
+                np.max(np.abs(ob - beta[b])) < 1e-9
+        assert same_sweeps >= B - 2
+
+
+def test_strong_cd_hand_kat():
+    # SURVEY.md 8c item 4
+    beta = api.strong_coordinate_descent(None, None, np.zeros(1), 1.0, 0.5, np.array([[2.0]]), np.array([4.0]),
+                                         tol=1e-12)
+    assert beta[0] == pytest.approx(1.4, abs=1e-14)
+
+
+def test_strong_cd_kkt_at_tight_tolerance():
+    from tests.test_oracle_cd import kkt_violation, _problem
+    X, y = _problem(400, 30, 7)
+    G, q = X.T @ X, X.T @ y
+    for lam, alpha in ((5.0, 0.4), (0.9 * np.max(np.abs(q)) / 0.5, 0.5), (4.0 * np.max(np.abs(q)), 0.5)):
+        beta = api.strong_coordinate_descent(X, y, np.ones(30), lam, alpha, G, q, tol=1e-13)
+        assert kkt_violation(G, q, beta, lam, alpha) < 1e-5
+
+
+CASES = {
+    "plain": dict(),
+    "na": dict(with_na=True),
+    "interaction": dict(interaction_idx=(1, 2)),
+    "unmasked": dict(tuning=0),
+    "ridge": dict(alpha=0.0),
+    "ridge_unmasked": dict(alpha=0.0, tuning=0),
+    "k17": dict(K=17, n=90, p=120),
+    "three_cov": dict(level_counts=(4, 3, 5), n=120, p=100),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_optimize_one_iteration(oracle, case):
+    w = workloads.small(**CASES[case])
+    A, C = _rand_factors(w, 5, scale=0.3)   # non-trivial start so that every term of the update matters
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize([a.copy(order="F") for a in A], C.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=w.tuning,
+                      max_iter=0, seed=17)
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, A, C, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          tuning=w.tuning, max_iter=0, seed=17)
+    assert got["iters"] == ref["iters"]
+    for i, a in enumerate(ref["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-9
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-9
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_optimize_31_iterations(oracle, case):
+    w = workloads.small(**CASES[case])
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize([a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha,
+                      tuning=w.tuning, max_iter=30, seed=23)
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          tuning=w.tuning, max_iter=30, seed=23)
+    assert got["iters"] == ref["iters"] == 31
+    assert list(got["traj"][:, 0]) == [-1, 0, 10, 20, 30]
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+    assert np.array_equal(got["traj"][:, 9], ref["traj"][:, 9])      # same decay schedule
+    for i, a in enumerate(ref["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-6
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-6
+    assert got["loss"] == pytest.approx(ref["loss"], rel=1e-9)
+    if w.tuning == 0:
+        assert np.isnan(got["test_rmse"])
+
+
+def test_inplace_update_and_oneshot_operator(oracle):
+    # the reference mutates cfd_factors / column_factor in place (src/optimize.cpp:283-284) and returns copies
+    w = workloads.small()
+    A = [a.copy(order="F") for a in w.A0]
+    C = w.C0.copy(order="F")
+    out = api.optimize(w.X, A, C, w.levels, None, w.M_train, w.M_test, 0, w.K, w.lam, w.lam, w.alpha, 1, 1e-10, 1e-5,
+                       3, seed=5)
+    assert np.array_equal(C, out["column_factor"]) and not np.array_equal(C, w.C0)
+    assert np.array_equal(A[0], out["row_matrices"]["factor0"])
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          max_iter=3, seed=5)
+    assert relerr(C, ref["column_factor"]) < 1e-8
+
+
+def test_global_tol_early_stop(oracle):
+    w = workloads.small()
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=200, global_tol=1e-3, seed=1)
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          max_iter=200, global_tol=1e-3, seed=1)
+    assert got["iters"] == ref["iters"] and got["traj"].shape == ref["traj"].shape
+
+
+def test_bad_arguments_return_status():
+    w = workloads.small()
+    lev = w.levels.copy()
+    lev[0, 0] = 0
+    with pytest.raises(_lib.InsiderError) as e:
+        api.InsiderData(w.X, lev, w.M_train, w.M_test, n_levels=w.n_levels)
+    assert e.value.status == _lib.ERR_ARG
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    with pytest.raises(_lib.InsiderError) as e:
+        ds.optimize(*_cp(w), w.K, tuning=5)
+    assert e.value.status == _lib.ERR_ARG
+    with pytest.raises(_lib.InsiderError) as e:
+        ds.optimize(*_cp(w), w.K, inc_continuous=1)
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+    ds.close()
+
+
+def test_handle_reuse_across_ranks_like_tune(oracle):
+    # tune() keeps X/M resident and changes K / lambda / alpha between calls (R/insider.R:98-174)
+    w = workloads.small(n=80, p=100, K=6)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    for K, lam, alpha in ((3, 1.0, 0.2), (6, 3.0, 0.5), (3, 0.1, 0.0)):
+        A0, C0 = workloads.init_factors(w.n_levels, K, w.p, seed=K)
+        got = ds.optimize([a.copy(order="F") for a in A0], C0.copy(order="F"), K, lam, lam, alpha, max_iter=5, seed=2)
+        ref = oracle.optimize(w.X, w.levels, w.n_levels, A0, C0, w.M_train, w.M_test, lam, lam, alpha, max_iter=5,
+                              seed=2)
+        assert relerr(got["column_factor"], ref["column_factor"]) < 1e-7
+        assert got["test_rmse"] == pytest.approx(ref["test_rmse"], rel=1e-9)
+    ds.close()
+
+
+# ---- BASELINE config c2 at full size: size-independent properties (the oracle is too slow there) --------------
+@pytest.fixture(scope="module")
+def c2():
+    return workloads.make("c2")
+
+
+def test_c2_full_size_properties(c2):
+    w = c2
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=20, seed=3)
+    ds.close()
+    tr = got["traj"]
+    assert np.all(np.diff(tr[:, 7]) < 0)                      # checkpoint losses decrease
+    A = [got["row_matrices"][f"factor{i}"] for i in range(len(w.A0))]
+    C = got["column_factor"]
+    R = sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]))
+    resid = w.X - R @ C
+    sse = float(np.sum(resid[w.M_train != 0] ** 2))
+    # loss components recomputed independently in numpy from the returned factors
+    assert tr[-1, 3] == pytest.approx(sse / 2, rel=1e-10)
+    assert tr[-1, 4] == pytest.approx(w.lam * sum(np.sum(a ** 2) for a in A) / 2, rel=1e-12)
+    assert tr[-1, 5] == pytest.approx(w.lam * (1 - w.alpha) * np.sum(C ** 2) / 2, rel=1e-12)
+    assert tr[-1, 6] == pytest.approx(w.lam * w.alpha * np.sum(np.abs(C)), rel=1e-12)
+    assert got["test_rmse"] == pytest.approx(np.sqrt(np.mean(resid[w.M_test != 0] ** 2)), rel=1e-10)
+    assert got["train_rmse"] == pytest.approx(np.sqrt(sse / np.count_nonzero(w.M_train)), rel=1e-10)
+    assert got["test_rmse"] < 1.2                              # noise sd is 1: the fit generalises
+
+
+def test_c2_all_ones_mask_equals_unmasked(c2):
+    w = c2
+    ones = np.ones_like(w.M_train)
+    zeros = np.zeros_like(w.M_test)
+    ds = api.InsiderData(w.X, w.levels, ones, zeros)
+    r1 = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=10, seed=3)
+    r0 = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=0, max_iter=10, seed=3)
+    ds.close()
+    assert relerr(r1["column_factor"], r0["column_factor"]) < 1e-9
+    np.testing.assert_allclose(r1["traj"][:, 3:8], r0["traj"][:, 3:8], rtol=1e-10)

@@ -1,0 +1,113 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every declared symbol, the host logic of the
+API mirror behaves like the reference's R code, and the product fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from insider_amd import _lib, api, workloads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    ge.build()
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "insider_hip.h")).read()
+    declared = set(re.findall(r"\b(insider_hip_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS)
+    for s in declared:
+        assert getattr(lib, s) is not None
+    assert b"gfx950" in lib.insider_hip_version()
+
+
+def test_product_never_imports_oracle():
+    # only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "insider_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("CPU oracle and the HIP kernels", ""), f
+
+
+def test_fails_loudly_without_gpu(lib):
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    w = workloads.small()
+    with pytest.raises(_lib.InsiderError) as e:
+        api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    assert e.value.status == _lib.ERR_NO_DEVICE
+    with pytest.raises(_lib.InsiderError):
+        api.strong_coordinate_descent(None, None, np.zeros(3), 1.0, 0.5, np.eye(3), np.ones(3))
+
+
+def test_argument_errors_do_not_exit():
+    # the reference prints and exit(1)s on these (src/optimize.cpp:249-251,270-272)
+    w = workloads.small()
+    with pytest.raises(_lib.InsiderError, match="tuning should be either 0 or 1"):
+        api.optimize(w.X, w.A0, w.C0, w.levels, None, w.M_train, w.M_test, 0, w.K, tuning=2)
+    with pytest.raises(_lib.InsiderError, match="inc_continuous"):
+        api.optimize(w.X, w.A0, w.C0, w.levels, None, w.M_train, w.M_test, 3, w.K)
+
+
+def test_ratio_splitter_semantics():
+    # R/utils.R:78-117
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((30, 20))
+    d[rng.random(d.shape) < 0.1] = np.nan
+    d[:, 3] = np.nan                      # a column that becomes all-zero is dropped
+    out = api.ratio_splitter(d, ratio=0.2)
+    keep = out["kept_columns"]
+    assert not keep[3] and keep.sum() == 19
+    tr, te, na = out["train_indicator"], out["test_indicator"], out["na_indicator"]
+    assert not (tr & te).any() and not (tr & na).any() and not (te & na).any()
+    assert (tr | te | na).all()
+    n_existing = np.count_nonzero(~np.isnan(d))
+    assert te.sum() <= int(np.floor(n_existing * 0.2))          # some may fall in the dropped column
+    assert np.array_equal(out["testset"] != 0, te & (out["testset"] != 0))
+    again = api.ratio_splitter(d, ratio=0.2)
+    assert np.array_equal(again["test_indicator"], te)          # set.seed(123) analogue: deterministic
+
+
+def test_insider_object_and_interaction_column():
+    # R/insider.R:28-40: interaction indicator inserted as the SECOND column
+    rng = np.random.default_rng(1)
+    conf = workloads.cyclic_levels(24, (3, 2, 4))
+    data = rng.standard_normal((24, 10))
+    obj = api.insider(data, conf, interaction_idx=(1, 2))
+    assert obj["confounder"].shape == (24, 4)
+    assert np.array_equal(obj["confounder"][:, 0], conf[:, 0]) and np.array_equal(obj["confounder"][:, 2:], conf[:, 1:])
+    inter = obj["confounder"][:, 1]
+    pairs = {}
+    for a, b, k in zip(conf[:, 0], conf[:, 1], inter):
+        assert pairs.setdefault((a, b), k) == k
+    assert len(set(pairs.values())) == len(pairs) == inter.max()
+    assert obj["params"] == dict(global_tol=1e-9, sub_tol=1e-5, tuning_iter=30, max_iter=50000)
+    with pytest.raises(ValueError, match="out of the range"):
+        api.insider(data, conf, interaction_idx=(1, 9))
+    with pytest.raises(ValueError, match="greater than or equal to 2"):
+        api.insider(data, conf, interaction_idx=(1,))
+
+
+def test_tune_argument_checks():
+    obj = api.Insider(params=dict(global_tol=1e-9, sub_tol=1e-5, tuning_iter=3, max_iter=5))
+    with pytest.raises(ValueError, match="TUNNING"):
+        api.tune(obj, latent_dimension=None, lambda_=[1, 2])
+    with pytest.raises(ValueError, match="TUNNING"):
+        api.tune(obj, latent_dimension=np.array([5]), lambda_=1.0, alpha=0.1)
+
+
+def test_workload_configs():
+    w = workloads.make("c1")
+    assert w.X.shape == (377, 5000) and list(w.n_levels) == [2, 16, 8, 107] and w.K == 23 and w.tuning == 0
+    s = workloads.make(n=50, p=80, level_counts=(5, 2), K=3, f=0.1)
+    assert s.M_test.sum() == int(np.floor(50 * 80 * 0.1)) and not (s.M_train & s.M_test).any()
+    slab = workloads.make(n=50, p=3000, level_counts=(5, 2), K=3, f=0.1, gene_range=(1000, 2100))
+    full = workloads.make(n=50, p=3000, level_counts=(5, 2), K=3, f=0.1)
+    assert np.array_equal(slab.X, full.X[:, 1000:2100]) and np.array_equal(slab.M_train, full.M_train[:, 1000:2100])
