@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py — outer-iterations/sec of the INSIDER factorisation hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
+
+A "step" is one outer iteration of the reference's optimize() (src/optimize.cpp:325-410): all covariate row
+updates, the column update and the amortised checkpoint work.  The timed region is ONE optimize() call of K outer
+iterations (max_iter = K-1; K = 31 is exactly a tuning_iter = 30 call of tune(), R/insider.R:163-164) with X, the
+masks and the level tables already resident in HBM; W warm-up iterations run first through a separate call.
+N > 1: one process per GPU (torchrun), genes sharded across ranks (strong scaling: the total workload is fixed),
+RCCL all-reduces of the per-level normal equations and of the loss terms.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the masked Gram/XtY reduction kernel (the kernel
+BASELINE.json's metric names), timed live with HIP events on the library's stream; `cd_kernel` reports the
+elastic-net sweep kernel, which dominates wall time at these sizes; `cpu_baseline` times the CPU oracle (the
+reference's formulation) on a bounded gene sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a copy kernel)
+FP64_PEAK_TFLOPS = 78.6    # fp64 vector == fp64 matrix peak on MI355X (vendor figure)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=31)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-genes", type=int, default=0, help="0 = choose for ~10-30 s of CPU work")
+    ap.add_argument("--seed", type=int, default=20240301)
+    return ap.parse_args()
+
+
+def cpu_baseline(name, lam, alpha, n_cores):
+    """The CPU oracle (reference formulation: residual-form CD, cube slices, materialised residual) on a bounded
+    sample: the first `genes` genes of the same workload, all samples, 1 outer iteration.  Every per-iteration
+    cost of the reference scales linearly in the number of genes, so iterations/s of the full workload =
+    iterations/s of the sample * genes / p."""
+    from insider_amd import workloads
+    from oracle import c_oracle
+    cn, cp = workloads.CONFIGS[name][0], workloads.CONFIGS[name][1]
+    genes = 8
+    w = workloads.make(name, gene_range=(0, genes))
+    row_t, col_t = min(10, n_cores), min(30, n_cores)      # the reference's hard-coded 10 / 30 (src/optimize.cpp:140,376)
+    t0 = time.perf_counter()
+    res = c_oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, lam, lam, alpha, tuning=w.tuning,
+                            max_iter=0, seed=1, row_threads=row_t, col_threads=col_t)
+    dt = time.perf_counter() - t0
+    its = 1.0 / dt * genes / cp
+    return {"value": its, "unit": "outer-iterations/s", "cores": col_t, "kind": "port",
+            "sample": f"{name}: first {genes} of {cp} genes x all {cn} samples, 1 outer iteration "
+                      f"({res['total_sweeps']} CD sweeps), {dt:.1f} s wall, scaled by {genes}/{cp}; "
+                      f"row step {row_t} threads / column step {col_t} threads (reference: 10 / 30)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torchrun --nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from insider_amd import api, dist as idist, workloads
+
+    name = args.workload
+    n, p_total, _, _, K, lam, alpha, tuning, f = workloads.CONFIGS[name]
+    lo, hi = idist.shard_range(p_total, rank, world)
+    t0 = time.perf_counter()
+    w = workloads.make(name, gene_range=(lo, hi))
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, device=local_rank)
+    t_up = time.perf_counter() - t0
+    idist.attach(ds, lo, rank, world, device=local_rank)
+    ds.set_option("profile", 1)
+    p_loc = hi - lo
+
+    def run(iters, seed):
+        A = [a.copy(order="F") for a in w.A0]
+        C = w.C0.copy(order="F")
+        return ds.optimize(A, C, K, lam, lam, alpha, tuning=tuning, max_iter=iters - 1, global_tol=-1.0, seed=seed)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup, args.seed)
+    sync()
+    t0 = time.perf_counter()
+    res = run(args.steps, args.seed)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ds.profile()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert res["iters"] == args.steps, (res["iters"], args.steps)
+
+    if rank == 0:
+        gram_ms = (prof["col_stats_ms"] / max(prof["col_stats_launches"], 1))
+        # algorithmic bytes / flops of ONE launch of the masked Gram/XtY kernel over this rank's genes
+        # (SURVEY.md 8d): 8np (X) + np (uint8 mask) + 8nK (R once) + stats out; flops 2 f np K(K+1)/2 + 2 f np K
+        T = K * (K + 1) // 2
+        b_col = 8.0 * n * p_loc + 1.0 * n * p_loc + 8.0 * n * K + 8.0 * p_loc * (T + K)
+        fl = 2.0 * f * n * p_loc * T + 2.0 * f * n * p_loc * K
+        ach = b_col / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(name, {}).get("col_stats_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "outer-iterations/sec (masked INSIDER fit, 10k x 50k, K=30)" if name == "c3" else
+                      f"outer-iterations/sec ({name})",
+            "value": args.steps / dt, "unit": "outer-iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{name}: {n}x{p_total} fp64, K={K}, lambda={lam}, alpha={alpha}, "
+                                   f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}",
+                       "genes_per_gpu": p_loc, "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
+                       "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
+            "roofline": {"kernel": "k_line_stats (masked Gram/XtY complement statistics, column side)",
+                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],
+                         "fp64_tflops": fl / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
+                         "fp64_frac": fl / (gram_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gram_ms > 0 else 0.0,
+                         "row_side_avg_launch_ms": prof["row_stats_ms"] / max(prof["row_stats_launches"], 1)},
+            "cd_kernel": {"kernel": "k_cd_cols (elastic-net coordinate sweeps, one wave per gene group)",
+                          "avg_launch_ms": prof["cd_ms"] / max(prof["cd_launches"], 1),
+                          "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,
+                          "coordinate_updates_per_s": prof["sweeps"] * K / max(prof["cd_ms"] * 1e-3, 1e-9),
+                          "share_of_wall": prof["cd_ms"] / (dt * 1e3)},
+            "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"],
+            "setup_s": {"generate": t_gen, "upload_and_precompute": t_up},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(name, lam, alpha, os.cpu_count() or 1)
+            except Exception as e:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"value": None, "unit": "outer-iterations/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    ds.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

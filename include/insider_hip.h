@@ -118,11 +118,12 @@ int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *
  * matrix X and outcome y of the reference signature enter only through XtX = X'X and Xty = X'y, which the
  * reference's callers always pass alongside (src/optimize.cpp:228,246), so they are not taken here.
  *   XtX    nprob blocks of K x K (column-major; symmetric), Xty / wstart / beta_out nprob blocks of K
- *   unit0  subproblem b uses sweep-order key unit0 + b;  sweeps_out optional, nprob ints
+ *   seed, iter  key the per-sweep coordinate order (include/insider_perm.h; the same for every subproblem)
+ *   sweeps_out  optional, nprob ints
  */
 int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob,
-                          double lambda, double alpha, double tol, uint64_t seed, uint32_t unit0, uint32_t iter,
-                          int order_mode, int max_sweeps, int device, double *beta_out, int32_t *sweeps_out);
+                          double lambda, double alpha, double tol, uint64_t seed, uint32_t iter, int order_mode,
+                          int max_sweeps, int device, double *beta_out, int32_t *sweeps_out);
 
 /*
  * The masked Gram / XtY reductions on their own (for parity tests and profiling).
@@ -136,10 +137,16 @@ int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *ws
 int insider_hip_masked_gram_cols(insider_hip_handle *h, const double *R, int K, double *G_out, double *q_out);
 int insider_hip_masked_gram_rows(insider_hip_handle *h, const double *C, int K, double *H_out, double *b_out);
 
-/* Profile of the last insider_hip_optimize() call (option "profile" = 1).  out[0..7]:
- * {col kernel launches, col kernel total ms, row kernel launches, row kernel total ms,
- *  total optimize wall ms, outer iterations run, elastic-net sweeps total, reserved}. */
-int insider_hip_get_profile(insider_hip_handle *h, double *out8);
+/* Profile of the last insider_hip_optimize() call (option "profile" = 1), HIP-event timed on the library's stream.
+ * out[0..11]: {column-side masked-Gram launches, total ms, row-side masked-Gram launches, total ms,
+ *  column-solve (CD / ridge) launches, total ms, test-residual launches, total ms,
+ *  optimize() wall ms, outer iterations run, elastic-net sweeps total, reserved}. */
+int insider_hip_get_profile(insider_hip_handle *h, double *out12);
+
+/* Diagnostics: per-gene sweep counts of the last column update (p ints), and the HIP-event time in ms of the
+ * kernel launched by the calling process's last insider_hip_strong_cd(). */
+int insider_hip_get_sweeps(insider_hip_handle *h, int32_t *out);
+double insider_hip_last_cd_ms(void);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,14 @@
  * the 32-bit key below and the sweep visits active coordinates in ascending
  * key order.  The low 6 bits of a key are the coordinate index, so keys are
  * unique (K <= 64) and the order is a pure function of
- * (seed, unit = gene index, outer iteration, sweep counter).
+ * (seed, outer iteration, sweep counter).  It does NOT depend on the gene: the
+ * subproblems are independent, so sharing one fresh random order per sweep
+ * number across genes leaves every gene's own order sequence uniformly random
+ * (the reference's distribution) while letting the HIP kernel run several
+ * genes per wavefront in lock-step and read the order from a small
+ * precomputed table.  Sweeping "all coordinates in key order, skipping the
+ * inactive ones" is the same as a uniformly random order over the active set
+ * (src/coordinate_descent.cpp:89-92).
  *
  * Pure uint32 wrap-around arithmetic: bit-identical in gcc and in hipcc
  * device code.
@@ -38,10 +45,10 @@ INSIDER_HD uint32_t insider_h32(uint32_t x)
     return x;
 }
 
-/* Per-(seed, unit, iteration, sweep) base word; uniform across coordinates. */
-INSIDER_HD uint32_t insider_perm_base(uint64_t seed, uint32_t unit, uint32_t iter, uint32_t sweep)
+/* Per-(seed, iteration, sweep) base word; uniform across coordinates and genes. */
+INSIDER_HD uint32_t insider_perm_base(uint64_t seed, uint32_t iter, uint32_t sweep)
 {
-    uint32_t b = insider_h32((uint32_t)seed ^ (0x9E3779B9U * unit));
+    uint32_t b = insider_h32((uint32_t)seed ^ 0x9E3779B9U);
     b = insider_h32(b ^ (uint32_t)(seed >> 32) ^ (0x85EBCA6BU * iter));
     b = insider_h32(b + 0xC2B2AE35U * sweep);
     return b;

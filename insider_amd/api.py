@@ -115,10 +115,17 @@ class InsiderData:
         return H, b
 
     def profile(self):
-        out = np.zeros(8)
+        out = np.zeros(12)
         _lib.check(_lib.load().insider_hip_get_profile(self._h, _lib.ptr(out)))
-        return dict(col_launches=int(out[0]), col_ms=out[1], row_launches=int(out[2]), row_ms=out[3],
-                    wall_ms=out[4], iters=int(out[5]), sweeps=int(out[6]))
+        return dict(col_stats_launches=int(out[0]), col_stats_ms=out[1], row_stats_launches=int(out[2]),
+                    row_stats_ms=out[3], cd_launches=int(out[4]), cd_ms=out[5], test_launches=int(out[6]),
+                    test_ms=out[7], wall_ms=out[8], iters=int(out[9]), sweeps=int(out[10]))
+
+    def sweeps(self):
+        """Per-gene sweep counts of the last column update."""
+        out = np.zeros(self.p, dtype=np.int32)
+        _lib.check(_lib.load().insider_hip_get_sweeps(self._h, _lib.ptr(out, C.c_int32)))
+        return out
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -155,7 +162,7 @@ def optimize(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, 
         ds.close()
 
 
-def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol=1e-5, seed=DEFAULT_SEED, unit=0, it=0,
+def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol=1e-5, seed=DEFAULT_SEED, it=0,
                               order_mode=0, max_sweeps=10000, device=0, return_sweeps=False):
     """strong_coordinate_descent() of R/RcppExports.R:8-10 (src/coordinate_descent.cpp:56-127).
 
@@ -175,7 +182,7 @@ def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol=1e-5, 
     beta = np.zeros((B, K))
     sw = np.zeros(B, dtype=np.int32)
     _lib.check(_lib.load().insider_hip_strong_cd(_lib.ptr(G), _lib.ptr(q), _lib.ptr(w), K, B, float(lambda_),
-                                                 float(alpha), float(tol), int(seed), int(unit), int(it),
+                                                 float(alpha), float(tol), int(seed), int(it),
                                                  int(order_mode), int(max_sweeps), int(device), _lib.ptr(beta),
                                                  _lib.ptr(sw, C.c_int32)))
     if single:

@@ -7,6 +7,8 @@
 // checkpoints (every 10th iteration) and around the optional cross-rank all-reduce.
 #include "insider_kernels.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -23,6 +25,7 @@ using namespace insider;
 namespace {
 
 thread_local std::string g_err;
+double g_last_cd_ms = 0.0;
 
 int fail(int code, const std::string &msg)
 {
@@ -78,10 +81,17 @@ struct insider_hip_handle {
     // factor-dependent workspace for the current K
     int K = 0, NB = 0, KP = 0, nseg = 1, seg_len = 0;
     double *Astack = nullptr, *R = nullptr, *C = nullptr, *RtR = nullptr, *CCt = nullptr, *Qfull = nullptr, *SC = nullptr;
-    double *stat = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
+    double *stat = nullptr, *stat_col = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
     double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
     int *sweeps = nullptr, *failflag = nullptr;
     unsigned long long *sweep_total = nullptr;
+    uint8_t *order = nullptr;
+    int order_rows = 0;
+    // gene scheduling for the CD kernel: genes sorted by the sweep count of their previous solve
+    int *gene_ids = nullptr, *gene_perm = nullptr, *sweeps_sorted = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    bool have_perm = false;
     size_t stage_count = 0;
     int gram_blocks_p = 0, gram_blocks_n = 0, sc_blocks = 0;
     // sharding
@@ -92,21 +102,29 @@ struct insider_hip_handle {
     // options
     int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0;
     // profile of the last optimize()
-    std::vector<hipEvent_t> ev_col, ev_row;
-    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> ev_col, ev_row, ev_cd, ev_test;
+    double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
 
 void free_workspace(insider_hip_handle *h)
 {
-    double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->gram_part,
+    double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
                        &h->sc_part, &h->lvl_part, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->sweeps) (void)hipFree(h->sweeps);
     if (h->failflag) (void)hipFree(h->failflag);
     if (h->sweep_total) (void)hipFree(h->sweep_total);
+    if (h->order) (void)hipFree(h->order);
+    h->order = nullptr;
+    h->order_rows = 0;
+    for (void *q : {(void *)h->gene_ids, (void *)h->gene_perm, (void *)h->sweeps_sorted, h->sort_tmp}) if (q) (void)hipFree(q);
+    h->gene_ids = h->gene_perm = h->sweeps_sorted = nullptr;
+    h->sort_tmp = nullptr;
+    h->sort_tmp_bytes = 0;
+    h->have_perm = false;
     h->sweep_total = nullptr;
     h->sweeps = nullptr;
     h->failflag = nullptr;
@@ -139,6 +157,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->Qfull, (size_t)h->p * KP))) return rc;
     if ((rc = dmalloc(&h->SC, (size_t)h->SL * KP))) return rc;
     if ((rc = dmalloc(&h->stat, (size_t)nseg * h->n * STAT))) return rc;
+    if ((rc = dmalloc(&h->stat_col, (size_t)h->p * STAT))) return rc;
     if ((rc = dmalloc(&h->gram_part, (size_t)std::max(h->gram_blocks_p, h->gram_blocks_n) * KP * KP))) return rc;
     if ((rc = dmalloc(&h->sc_part, (size_t)h->sc_blocks * h->SL * KP))) return rc;
     if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP)))) return rc;
@@ -153,6 +172,20 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->sweeps, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->failflag, 1))) return rc;
     if ((rc = dmalloc(&h->sweep_total, 1))) return rc;
+    if ((rc = dmalloc(&h->gene_ids, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->sweeps_sorted, (size_t)h->p))) return rc;
+    {
+        std::vector<int> ids(h->p);
+        for (int64_t i = 0; i < h->p; ++i) ids[i] = (int)i;
+        HIPCHECK(hipMemcpy(h->gene_ids, ids.data(), (size_t)h->p * sizeof(int), hipMemcpyHostToDevice));
+        size_t bytes = 0;
+        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, h->sweeps, h->sweeps_sorted, h->gene_ids,
+                                                              h->gene_perm, (int)h->p, 0, 32, h->stream));
+        HIPCHECK(hipMalloc(&h->sort_tmp, bytes ? bytes : 1));
+        h->sort_tmp_bytes = bytes;
+    }
+    h->have_perm = false;
     // rows of the padded factor buffers beyond K must stay zero: C rows are gathered with pitch KP and the
     // pad genes of the transposed layout index rows p..ldp-1
     HIPCHECK(hipMemsetAsync(h->C, 0, (size_t)std::max<int64_t>(h->p, h->ldp) * KP * sizeof(double), h->stream));
@@ -211,45 +244,118 @@ int phase_R(insider_hip_handle *h)
     return INSIDER_OK;
 }
 
-int launch_col(insider_hip_handle *h, int masked, int mode, int checkpoint, const CdParams &cd, bool timed)
-{
-    ColArgs a;
-    a.vals = h->X;
-    a.codes = h->codes;
-    a.pitch = h->ldn;
-    a.p = (int)h->p;
-    a.K = h->K;
-    a.masked = masked;
-    a.R = h->R;
-    a.RtR = h->RtR;
-    a.Qfull = h->Qfull;
-    a.C = h->C;
-    a.yy = masked ? h->yy_train : h->yy_all;
-    a.mode = mode;
-    a.checkpoint = checkpoint;
-    a.cd = cd;
-    a.gene_offset = h->gene_offset;
-    a.sse_train = h->sse_train;
-    a.sse_test = h->sse_test;
-    a.b2 = h->b2;
-    a.b1 = h->b1;
-    a.sweeps = h->sweeps;
-    a.fail = h->failflag;
+struct Timer {   // HIP-event pair around one launch on the library's stream (option "profile")
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed && h->profile) {
+    int begin(insider_hip_handle *h, bool on)
+    {
+        if (!on || !h->profile) return INSIDER_OK;
         HIPCHECK(hipEventCreate(&e0));
         HIPCHECK(hipEventCreate(&e1));
         HIPCHECK(hipEventRecord(e0, h->stream));
+        return INSIDER_OK;
     }
-    NB_DISPATCH(h->NB, hipLaunchKernelGGL((k_col_update<NB_, WPB_>), dim3(cdiv(h->p, WPB_)), dim3(WPB_ * 64), 0,
-                                           h->stream, a));
-    KCHECK();
-    if (e0) {
+    int end(insider_hip_handle *h, std::vector<hipEvent_t> &into)
+    {
+        if (!e0) return INSIDER_OK;
         HIPCHECK(hipEventRecord(e1, h->stream));
-        h->ev_col.push_back(e0);
-        h->ev_col.push_back(e1);
+        into.push_back(e0);
+        into.push_back(e1);
+        return INSIDER_OK;
     }
-    if (timed && h->profile) {
+};
+
+int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode)
+{
+    if (h->order_rows < max_sweeps) {
+        if (h->order) (void)hipFree(h->order);
+        h->order = nullptr;
+        int rc = dmalloc(&h->order, (size_t)max_sweeps * 64);
+        if (rc) return rc;
+        h->order_rows = max_sweeps;
+    }
+    hipLaunchKernelGGL(k_order_table, dim3(cdiv(max_sweeps, 64)), dim3(64), 0, h->stream, seed, iter, K, max_sweeps,
+                       order_mode, h->order);
+    KCHECK();
+    return INSIDER_OK;
+}
+
+// masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
+int launch_col_stats(insider_hip_handle *h, bool timed)
+{
+    Timer t;
+    int rc = t.begin(h, timed);
+    if (rc) return rc;
+    rc = launch_line_stats(h, h->X, h->codes, h->ldn, (int)h->p, 1, (int)h->ldn, h->R, h->stat_col);
+    if (rc) return rc;
+    return t.end(h, h->ev_col);
+}
+
+// column update from the statistics: elastic-net CD (alpha > 0) or ridge (alpha == 0), or evaluation only
+int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambda, double alpha, double tol,
+                     int checkpoint, bool timed)
+{
+    const int NBLK = h->NB * (h->NB + 1) / 2, STAT = NBLK * 256;
+    Timer t;
+    int rc = t.begin(h, timed);
+    if (rc) return rc;
+    if (alpha == 0.0) {
+        RidgeArgs a;
+        a.stat = masked ? h->stat_col : nullptr;
+        a.stat_len = STAT;
+        a.p = (int)h->p;
+        a.K = h->K;
+        a.KP = h->KP;
+        a.RtR = h->RtR;
+        a.Qfull = h->Qfull;
+        a.C = h->C;
+        a.yy = masked ? h->yy_train : h->yy_all;
+        a.lambda = lambda;
+        a.solve = solve ? 1 : 0;
+        a.checkpoint = checkpoint;
+        a.sse_train = h->sse_train;
+        a.b2 = h->b2;
+        a.b1 = h->b1;
+        a.fail = h->failflag;
+        hipLaunchKernelGGL((k_ridge_cols<1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
+        KCHECK();
+        if (solve) HIPCHECK(hipMemsetAsync(h->sweeps, 0, (size_t)h->p * sizeof(int), h->stream));
+    } else {
+        ColArgs a;
+        a.stat = masked ? h->stat_col : nullptr;
+        a.stat_len = STAT;
+        a.p = (int)h->p;
+        a.K = h->K;
+        a.KP = h->KP;
+        a.RtR = h->RtR;
+        a.Qfull = h->Qfull;
+        a.C = h->C;
+        a.yy = masked ? h->yy_train : h->yy_all;
+        a.mode = solve ? COL_CD : COL_EVAL;
+        a.checkpoint = checkpoint;
+        a.cd.lambda = lambda;
+        a.cd.alpha = alpha;
+        a.cd.tol = tol;
+        a.cd.max_sweeps = h->max_sweeps;
+        a.cd.order = h->order;
+        a.sse_train = h->sse_train;
+        a.b2 = h->b2;
+        a.b1 = h->b1;
+        a.sweeps = h->sweeps;
+        a.gene_perm = (solve && h->have_perm) ? h->gene_perm : nullptr;
+        if (h->K <= 16) hipLaunchKernelGGL((k_cd_cols<16, 4>), dim3(cdiv(h->p, 16)), dim3(256), 0, h->stream, a);
+        else if (h->K <= 32) hipLaunchKernelGGL((k_cd_cols<32, 2>), dim3(cdiv(h->p, 4)), dim3(128), 0, h->stream, a);
+        else hipLaunchKernelGGL((k_cd_cols<64, 1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
+        KCHECK();
+    }
+    if ((rc = t.end(h, h->ev_cd))) return rc;
+    if (solve && alpha != 0.0) {
+        // schedule the next solve longest-first, genes of similar length sharing a wave (stable sort: deterministic)
+        size_t bytes = h->sort_tmp_bytes;
+        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweeps, h->sweeps_sorted,
+                                                              h->gene_ids, h->gene_perm, (int)h->p, 0, 32, h->stream));
+        h->have_perm = true;
+    }
+    if (timed && solve && h->profile) {
         hipLaunchKernelGGL(k_accum_sweeps, dim3(1), dim3(256), 0, h->stream, (const int *)h->sweeps, (int)h->p,
                            h->sweep_total);
         KCHECK();
@@ -257,22 +363,31 @@ int launch_col(insider_hip_handle *h, int masked, int mode, int checkpoint, cons
     return INSIDER_OK;
 }
 
+// sum over test entries of the squared residual per gene (evaluate(), src/utils.cpp:67); checkpoints only
+int launch_test_sse(insider_hip_handle *h, int masked, bool timed)
+{
+    if (!masked) {
+        HIPCHECK(hipMemsetAsync(h->sse_test, 0, (size_t)h->p * sizeof(double), h->stream));
+        return INSIDER_OK;
+    }
+    Timer t;
+    int rc = t.begin(h, timed);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_test_sse<4>), dim3(cdiv(h->p, 4)), dim3(256), 0, h->stream, (const double *)h->X,
+                       (const uint8_t *)h->codes, h->ldn, (int)h->p, (const double *)h->R, (const double *)h->C, h->K,
+                       h->KP, h->sse_test);
+    KCHECK();
+    return t.end(h, h->ev_test);
+}
+
 int launch_row_stats(insider_hip_handle *h, bool timed)
 {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed && h->profile) {
-        HIPCHECK(hipEventCreate(&e0));
-        HIPCHECK(hipEventCreate(&e1));
-        HIPCHECK(hipEventRecord(e0, h->stream));
-    }
-    int rc = launch_line_stats(h, h->Xt, h->codes_t, h->ldp, (int)h->n, h->nseg, h->seg_len, h->C, h->stat);
+    Timer t;
+    int rc = t.begin(h, timed);
     if (rc) return rc;
-    if (e0) {
-        HIPCHECK(hipEventRecord(e1, h->stream));
-        h->ev_row.push_back(e0);
-        h->ev_row.push_back(e1);
-    }
-    return INSIDER_OK;
+    rc = launch_line_stats(h, h->Xt, h->codes_t, h->ldp, (int)h->n, h->nseg, h->seg_len, h->C, h->stat);
+    if (rc) return rc;
+    return t.end(h, h->ev_row);
 }
 
 int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
@@ -375,10 +490,10 @@ int check_fail_flag(insider_hip_handle *h)
 
 void clear_events(insider_hip_handle *h)
 {
-    for (auto e : h->ev_col) (void)hipEventDestroy(e);
-    for (auto e : h->ev_row) (void)hipEventDestroy(e);
-    h->ev_col.clear();
-    h->ev_row.clear();
+    for (auto *v : {&h->ev_col, &h->ev_row, &h->ev_cd, &h->ev_test}) {
+        for (auto e : *v) (void)hipEventDestroy(e);
+        v->clear();
+    }
 }
 
 }  // namespace
@@ -629,20 +744,12 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
                        KP, h->C);
     KCHECK();
 
-    CdParams cd;
-    cd.lambda = lambda2;
-    cd.alpha = alpha;
-    cd.tol = sub_tol;
-    cd.seed = seed;
-    cd.iter = 0;
-    cd.max_sweeps = h->max_sweeps;
-    cd.order_mode = h->order_mode;
-    const int solve_mode = alpha == 0.0 ? COL_RIDGE : COL_CD;
-
     // ---- fit of the initial values (src/optimize.cpp:320-323) ----------------------------------------------------
     LossOut lo;
     if ((rc = phase_R(h))) return rc;
-    if ((rc = launch_col(h, masked, COL_EVAL, 1, cd, false))) return rc;
+    if (masked) if ((rc = launch_col_stats(h, false))) return rc;
+    if ((rc = launch_col_solve(h, masked, false, lambda2, alpha, sub_tol, 1, false))) return rc;
+    if ((rc = launch_test_sse(h, masked, false))) return rc;
     if ((rc = loss_checkpoint(h, tuning, lambda1, lambda2, alpha, &lo))) return rc;
     double loss = lo.loss, pre_loss, decay = 1.0;
     double train_rmse = lo.train_rmse, test_rmse = lo.test_rmse;
@@ -681,10 +788,12 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         // ---- column step (:365-378) -------------------------------------------------------------------------------
         if ((rc = phase_R(h))) return rc;
         const int checkpoint = iter % 10 == 0;
-        cd.tol = sub_tol * decay;                                                               // :376
-        cd.iter = iter;
-        if ((rc = launch_col(h, masked, solve_mode, checkpoint, cd, true))) return rc;
+        if (alpha != 0.0)
+            if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
+        if (masked) if ((rc = launch_col_stats(h, true))) return rc;
+        if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true))) return rc;  // :376
         if (checkpoint) {                                                                       // :381-408
+            if ((rc = launch_test_sse(h, masked, true))) return rc;
             pre_loss = loss;
             if ((rc = loss_checkpoint(h, tuning, lambda1, lambda2, alpha, &lo))) return rc;
             if ((rc = check_fail_flag(h))) return rc;
@@ -743,9 +852,11 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     };
     sum_events(h->ev_col, &h->prof[0], &h->prof[1]);
     sum_events(h->ev_row, &h->prof[2], &h->prof[3]);
-    h->prof[4] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
-    h->prof[5] = (double)std::min<uint64_t>((uint64_t)iter + 1, (uint64_t)max_iter + 1);
-    h->prof[6] = (double)sweeps_total;
+    sum_events(h->ev_cd, &h->prof[4], &h->prof[5]);
+    sum_events(h->ev_test, &h->prof[6], &h->prof[7]);
+    h->prof[8] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+    h->prof[9] = (double)std::min<uint64_t>((uint64_t)iter + 1, (uint64_t)max_iter + 1);
+    h->prof[10] = (double)sweeps_total;
     clear_events(h);
     return INSIDER_OK;
 }
@@ -768,7 +879,7 @@ int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *
 }
 
 int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob, double lambda,
-                          double alpha, double tol, uint64_t seed, uint32_t unit0, uint32_t iter, int order_mode,
+                          double alpha, double tol, uint64_t seed, uint32_t iter, int order_mode,
                           int max_sweeps, int device, double *beta_out, int32_t *sweeps_out)
 {
     if (!XtX || !Xty || !wstart || !beta_out) return fail(INSIDER_ERR_ARG, "null argument");
@@ -788,21 +899,40 @@ int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *ws
     HIPCHECK(hipMemcpy(dG, XtX, (size_t)nprob * K * K * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dq, Xty, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dw, wstart, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
+    const int ms = max_sweeps < 1 ? 1 : max_sweeps;
+    uint8_t *dord = nullptr;
+    if ((rc = dmalloc(&dord, (size_t)ms * 64))) return rc;
+    hipLaunchKernelGGL(k_order_table, dim3(cdiv(ms, 64)), dim3(64), 0, 0, seed, iter, K, ms, order_mode, dord);
+    KCHECK();
     CdParams cd;
     cd.lambda = lambda;
     cd.alpha = alpha;
     cd.tol = tol;
-    cd.seed = seed;
-    cd.iter = iter;
-    cd.max_sweeps = max_sweeps < 1 ? 1 : max_sweeps;
-    cd.order_mode = order_mode;
-    hipLaunchKernelGGL((k_cd_batch<1>), dim3((unsigned)nprob), dim3(64), 0, 0, (const double *)dG, (const double *)dq,
-                       (const double *)dw, K, nprob, cd, unit0, db, ds);
+    cd.max_sweeps = ms;
+    cd.order = dord;
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    HIPCHECK(hipEventRecord(e0, 0));
+    if (K <= 16) hipLaunchKernelGGL((k_cd_batch<16, 4>), dim3(cdiv(nprob, 16)), dim3(256), 0, 0, (const double *)dG,
+                                    (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+    else if (K <= 32) hipLaunchKernelGGL((k_cd_batch<32, 2>), dim3(cdiv(nprob, 4)), dim3(128), 0, 0, (const double *)dG,
+                                         (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+    else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, (const double *)dG,
+                            (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
     KCHECK();
+    HIPCHECK(hipEventRecord(e1, 0));
     HIPCHECK(hipDeviceSynchronize());
+    {
+        float msf = 0;
+        (void)hipEventElapsedTime(&msf, e0, e1);
+        g_last_cd_ms = msf;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     HIPCHECK(hipMemcpy(beta_out, db, (size_t)nprob * K * sizeof(double), hipMemcpyDeviceToHost));
     if (sweeps_out) HIPCHECK(hipMemcpy(sweeps_out, ds, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(dG); (void)hipFree(dq); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(ds);
+    (void)hipFree(dG); (void)hipFree(dq); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dord);
     return INSIDER_OK;
 }
 
@@ -860,10 +990,22 @@ int insider_hip_masked_gram_rows(insider_hip_handle *h, const double *C, int K, 
     return masked_gram_common(h, false, C, K, H_out, b_out);
 }
 
-int insider_hip_get_profile(insider_hip_handle *h, double *out8)
+double insider_hip_last_cd_ms(void) { return g_last_cd_ms; }
+
+int insider_hip_get_sweeps(insider_hip_handle *h, int32_t *out)
 {
-    if (!h || !out8) return fail(INSIDER_ERR_ARG, "null");
-    for (int i = 0; i < 8; ++i) out8[i] = h->prof[i];
+    if (!h || !out) return fail(INSIDER_ERR_ARG, "null");
+    if (!h->sweeps) return fail(INSIDER_ERR_ARG, "no column update has run yet");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpy(out, h->sweeps, (size_t)h->p * sizeof(int), hipMemcpyDeviceToHost));
+    return INSIDER_OK;
+}
+
+int insider_hip_get_profile(insider_hip_handle *h, double *out12)
+{
+    if (!h || !out12) return fail(INSIDER_ERR_ARG, "null");
+    for (int i = 0; i < 12; ++i) out12[i] = h->prof[i];
     return INSIDER_OK;
 }
 

@@ -175,84 +175,191 @@ __device__ __forceinline__ void acc_to_lds(const d4 (&acc)[Geo<NB>::NBLK], doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// elastic-net coordinate descent, covariance form, one wave per subproblem
-// (strong_coordinate_descent, src/coordinate_descent.cpp:56-127)
+// elastic-net coordinate descent, covariance form (strong_coordinate_descent,
+// src/coordinate_descent.cpp:56-127)
 // ---------------------------------------------------------------------------------------------
+// At the workloads of BASELINE.json a subproblem needs thousands of sweeps (sub_tol = 1e-5 absolute on losses of
+// ~1e5), so the K-step sequential sweep is THE hot loop of the whole path.  Layout: a wavefront is split into
+// 64 / W groups of W lanes (W = 16, 32 or 64 >= K); each group owns one gene, lane l of the group owns
+// coordinate l.  All groups walk the same coordinate order (include/insider_perm.h: the order does not depend on
+// the gene; it is read from a table of max_sweeps rows precomputed per outer iteration), so the coordinate index
+// of a step is wave-uniform and the per-step work is ~15 vector instructions for 64 / W genes:
+//   reference residual form                  here
+//   u = dot(residual, X_k) + b_k XtX_kk :94  h_k, with h = Xty - offdiag(XtX) b kept per lane (XtX_kk b_k folded in)
+//   soft threshold / (XtX_kk + l2)  :99-104  every lane computes its own candidate; lane k's is broadcast
+//   residual -= d X_k              :106-109  h -= d * offdiag(XtX)[:, k]   (row k of the LDS copy, zero diagonal)
+//   |pre_loss - iter_loss| > tol        :114  exact loss change of the sweep from per-lane start/end values:
+//                                             dL = -1/2 sum_l db_l (g_l + g'_l) + penalties(b') - penalties(b)
 struct CdParams {
     double lambda, alpha, tol;
-    uint64_t seed;
-    uint32_t iter;
     int max_sweeps;
-    int order_mode;
+    const uint8_t *order;   // [max_sweeps][64]: row s, entry t = t-th coordinate of sweep s (all K coordinates)
 };
 
-// G: LDS, full symmetric, row pitch KP (>= K).  Lane l < K owns coordinate l: q = Xty_l, beta = warm start in,
-// solution out.  g_out = Xty - XtX beta (all lanes < K).  Returns the number of sweeps.
-//   reference residual form              covariance form used here
-//   dot(residual, X_k)          :94  ==  g_k = (Xty - XtX beta)_k
-//   residual -= d X_k          :107  ==  g -= d XtX[:,k]
-//   |pre_loss - iter_loss|     :114  ==  |sum over the sweep's updates of the exact loss change|
-__device__ __forceinline__ int cd_solve(const double *G, int KP, int K, double q, double &beta, double &g_out,
-                                        const CdParams &P, uint32_t unit, int lane)
+template <int W>
+__device__ __forceinline__ double group_bcast(double v, int k, int lane)
 {
-    const bool valid = lane < K;
+    if constexpr (W == 64) {
+        return readlane_d(v, k);
+    } else {
+        // ds_bpermute: 1 address op + 2 LDS-crossbar ops for all groups at once.  (Two v_readlane pairs plus a
+        // half-wave select have lower latency but cost 9 issue slots; the kernel is issue-bound at 2+ waves/SIMD.)
+        const int addr = ((lane & ~(W - 1)) + k) << 2;   // v_lshl_add_u32: one op (no width mask as in __shfl)
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+        hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+        return __hiloint2double(hi, lo);
+    }
+}
+
+// DPP lane moves (32-bit; fp64 values move as two halves)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over each 16-lane row, result in every lane of the row (quad swaps, half-mirror, mirror: 4 DPP steps)
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_mov_d<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov_d<0x141>(v);   // row_half_mirror
+    v += dpp_mov_d<0x140>(v);   // row_mirror
+    return v;
+}
+
+template <int W>
+__device__ __forceinline__ double group_sum(double v, int lane)
+{
+    v = row16_sum(v);
+    if constexpr (W == 16) return v;
+    if constexpr (W == 32) {
+        const double a = readlane_d(v, 0) + readlane_d(v, 16), b = readlane_d(v, 32) + readlane_d(v, 48);
+        return lane < 32 ? a : b;
+    } else {
+        return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+    }
+}
+
+template <int W>
+__device__ __forceinline__ double group_max(double v)
+{
+#pragma unroll
+    for (int o = W / 2; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Goff: this group's LDS block, K rows of pitch W: Goff[k * W + l] = XtX[k][l] with a ZERO diagonal; Gll = XtX[l][l].
+// q = Xty_l; beta: warm start in / solution out; g_out = (Xty - XtX beta)_l at the solution.
+// valid: lane owns a real coordinate of a real gene.  s_ord: per-wave LDS scratch of 64 ints.
+// Returns this group's sweep count.
+template <int W>
+__device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, double Gll, double q, double &beta,
+                                         double &g_out, bool valid, const CdParams &P, int lane)
+{
+    const int l = lane & (W - 1);
+    const uint64_t gmask = W == 64 ? ~0ull : (((1ull << (W & 63)) - 1ull) << (lane & ~(W - 1)));
+    const uint64_t lt = lanemask_lt(lane);
     const double la = P.lambda * P.alpha, l2 = P.lambda * (1.0 - P.alpha);
     const double aq = valid ? fabs(q) : 0.0;
-    const double mx = wave_max(aq);
-    const double thr = P.alpha * (2.0 * P.lambda - mx);                                // :74
+    const double mx = group_max<W>(aq);
+    const double thr = P.alpha * (2.0 * P.lambda - mx);                               // :74
     bool active = valid && !(aq < thr);
-    if (!active) beta = 0.0;                                                           // :78
-    double g = valid ? q : 0.0;                                                        // :79 (as Xty - XtX beta)
-    for (int m = 0; m < K; ++m) {
-        const double bm = readlane_d(beta, m);
-        if (bm != 0.0) g -= (valid ? G[m * KP + lane] : 0.0) * bm;
-    }
-    const double Gll = valid ? G[lane * KP + lane] : 1.0;
-    const double inv = 1.0 / (Gll + l2);
-    const uint64_t lt = lanemask_lt(lane);
-    int sweep = 0;
-    for (;;) {
-        const uint64_t amask = __ballot(active);                                       // :83
-        const int na = __popcll(amask);
-        double dl;
-        do {
-            int rank;
-            if (P.order_mode == 0) {                                                   // :89 randperm -> hashed order
-                const uint32_t base = insider_perm_base(P.seed, unit, P.iter, (uint32_t)sweep);
-                const uint32_t key = insider_perm_key(base, (uint32_t)lane);
-                rank = 0;
-                for (uint64_t m = amask; m; m &= m - 1) {
-                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(m));
-                    rank += kb < key;
-                }
-            } else {
-                rank = __popcll(amask & lt);
+    if (!active) beta = 0.0;                                                          // :78
+    double h = valid ? q : 0.0;                                                       // :79 in covariance form
+    for (int m = 0; m < K; ++m) h -= Goff[m * W + l] * group_bcast<W>(beta, m, lane);
+    const double rinv = 1.0 / (Gll + l2);
+    double inv = active ? rinv : 0.0;
+    bool run = (__ballot(valid) & gmask) != 0;   // group holds a gene
+    int sweep = 0, my_sweeps = 0;
+    double bfinal = beta, gfinal = 0.0;
+    uint32_t ordv = lane < K ? P.order[lane] : 0u;
+    while (__any(run)) {
+        const uint32_t ordn = (lane < K && sweep + 1 < P.max_sweeps) ? P.order[(size_t)(sweep + 1) * 64 + lane] : 0u;
+        // this sweep's coordinate list: the table row without the coordinates screened out in every group (:83)
+        uint64_t am = __ballot(active);
+        if constexpr (W == 32) am = (am | (am >> 32)) & 0xffffffffull;
+        if constexpr (W == 16) { am |= am >> 32; am |= am >> 16; am &= 0xffffull; }
+        const bool keep = lane < K && ((am >> ordv) & 1ull);
+        const uint64_t kb = __ballot(keep);
+        const int nk = __popcll(kb);
+        if (keep) s_ord[__popcll(kb & lt)] = (int)ordv;
+        if (lane == 0) s_ord[nk] = 0;   // dummy entry read by the last step's look-ahead
+        wave_sync();
+        const int ordc = s_ord[lane];   // lanes > nk hold stale entries: never used
+        wave_sync();
+        const double beta0 = beta, g0 = h - beta * Gll;
+        if (nk > 0) {
+            int k = __builtin_amdgcn_readlane(ordc, 0);
+            double gk = Goff[k * W + l];
+#pragma unroll 2
+            for (int t = 0; t < nk; ++t) {                                            // :91
+                // next step's coordinate and Gram row are fetched ahead: they do not depend on this step
+                const int kn = __builtin_amdgcn_readlane(ordc, t + 1);                // entry nk is a harmless dummy
+                const double gn = Goff[kn * W + l];
+                const double cand = copysign(fmax(fabs(h) - la, 0.0) * inv, h);       // :94-104
+                const double d = group_bcast<W>(cand - beta, k, lane);
+                h = fma(-d, gk, h);                                                   // :106-107
+                beta = l == k ? cand : beta;                                          // :108
+                k = kn;
+                gk = gn;
             }
-            ++sweep;
-            dl = 0.0;
-            for (int t = 0; t < na; ++t) {                                             // :91
-                const int k = __builtin_ctzll(__ballot(active && rank == t));
-                const double gcol = valid ? G[k * KP + lane] : 0.0;
-                const double gk = readlane_d(g, k), bk = readlane_d(beta, k);
-                const double Gkk = readlane_d(Gll, k), ik = readlane_d(inv, k);
-                const double u = gk + bk * Gkk;                                        // :94
-                const double au = fabs(u);
-                const double nb = au > la ? copysign(au - la, u) * ik : 0.0;           // :99-104
-                if (nb != bk) {                                                        // :106
-                    const double d = nb - bk;
-                    g -= d * gcol;                                                     // :107
-                    if (lane == k) beta = nb;                                          // :108
-                    dl += d * (0.5 * d * Gkk - gk) + 0.5 * l2 * (nb * nb - bk * bk) + la * (fabs(nb) - fabs(bk));
+        }
+        ++sweep;
+        const double g1 = h - beta * Gll, db = beta - beta0;
+        const double term = -0.5 * db * (g0 + g1) + 0.5 * l2 * (beta * beta - beta0 * beta0) +
+                            la * (fabs(beta) - fabs(beta0));
+        const double dloss = group_sum<W>(term, lane);                                // :112 as a difference
+        if (run) {
+            bool finish = sweep >= P.max_sweeps;
+            if (!finish && !(fabs(dloss) > P.tol)) {                                  // :114
+                const bool viol = valid && !active && fabs(g1) > P.alpha * P.lambda;  // :118-119 (grad = -g)
+                if ((__ballot(viol) & gmask) != 0) {                                  // :123
+                    if (viol) { active = true; inv = rinv; }
+                } else {
+                    finish = true;                                                    // :120-121
                 }
             }
-        } while (fabs(dl) > P.tol && sweep < P.max_sweeps);                            // :114
-        if (sweep >= P.max_sweeps) break;
-        const bool viol = valid && !active && fabs(g) > P.alpha * P.lambda;            // :118-119 (grad = -g)
-        if (!__any(viol)) break;                                                       // :120
-        active = active || viol;                                                       // :123
+            if (finish) {   // park the group: zero increments from now on
+                my_sweeps = sweep;
+                bfinal = beta;
+                gfinal = g1;
+                beta = 0.0;
+                inv = 0.0;
+                active = false;
+                run = false;
+            }
+        }
+        ordv = ordn;
     }
-    g_out = g;
-    return sweep;
+    beta = bfinal;
+    g_out = gfinal;
+    return my_sweeps;
+}
+
+// order[s][t] for s < nsweeps: all K coordinates in ascending key order (order_mode 0) or 0..K-1 (cyclic)
+__global__ void k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
+                              uint8_t *__restrict__ order)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsweeps) return;
+    uint32_t keys[64];
+    uint8_t ord[64];
+    const uint32_t base = insider_perm_base(seed, iter, (uint32_t)s);
+    for (int i = 0; i < K; ++i) { keys[i] = order_mode == 0 ? insider_perm_key(base, (uint32_t)i) : (uint32_t)i; ord[i] = (uint8_t)i; }
+    for (int i = 1; i < K; ++i) {
+        const uint32_t kk = keys[i];
+        const uint8_t v = ord[i];
+        int j = i - 1;
+        while (j >= 0 && keys[j] > kk) { keys[j + 1] = keys[j]; ord[j + 1] = ord[j]; --j; }
+        keys[j + 1] = kk;
+        ord[j + 1] = v;
+    }
+    for (int i = 0; i < 64; ++i) order[(size_t)s * 64 + i] = i < K ? ord[i] : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -330,155 +437,209 @@ k_line_stats(const double *__restrict__ vals, const uint8_t *__restrict__ codes,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel: fused column update (optimize_col, src/optimize.cpp:200-253) + checkpoint statistics
+// Kernel: column update (optimize_col, src/optimize.cpp:200-253) from the per-gene complement statistics
 // ---------------------------------------------------------------------------------------------
-enum ColMode { COL_EVAL = 0, COL_CD = 1, COL_RIDGE = 2 };
+enum ColMode { COL_EVAL = 0, COL_CD = 1 };
+
+// index of element (a, b) of the lower-block-stored symmetric statistics (see k_line_stats)
+__device__ __forceinline__ int stat_index(int a, int b)
+{
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int bi = a >> 4, bj = b >> 4;
+    int i = a & 15, j = b & 15;
+    if (bi == bj && i < j) { const int t = i; i = j; j = t; }   // diagonal blocks are stored full: either works
+    return (bi * (bi + 1) / 2 + bj) * 256 + i * 16 + j;
+}
 
 struct ColArgs {
-    const double *vals;      // X, gene-major lines of pitch ldn
-    const uint8_t *codes;
-    int64_t pitch;
-    int p;
-    int K;
-    int masked;              // tuning == 1: stream the line; 0: shared Gram, no streaming
-    const double *R;         // n x KP row factor rows (zero beyond K)
+    const double *stat;      // [p][stat_len] complement statistics of every gene, or null (tuning == 0)
+    int stat_len;
+    int p, K, KP;
     const double *RtR;       // KP x KP
     const double *Qfull;     // p x KP: R' x_j over ALL samples (from the per-level sums)
     double *C;               // p x KP: warm start in, solution out
-    const double *yy;        // p: sum of x^2 over train entries (masked) or all entries (unmasked)
+    const double *yy;        // p: sum of x^2 over train entries (masked) or over all entries
     int mode;                // ColMode
     int checkpoint;          // also produce per-gene loss statistics
     CdParams cd;
-    int64_t gene_offset;
-    double *sse_train, *sse_test, *b2, *b1;   // p each (checkpoint only)
+    double *sse_train, *b2, *b1;   // p each (checkpoint only)
     int *sweeps;             // p
-    int *fail;               // set to 1 if a ridge system was not positive definite
+    const int *gene_perm;    // launch slot -> gene (genes sorted by their last sweep count, longest first), or null
 };
 
-template <int NB, int WPB>
-__global__ void __launch_bounds__(WPB * 64) k_col_update(ColArgs a)
+template <int W, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_cd_cols(ColArgs a)
 {
-    constexpr int KP = Geo<NB>::KP, NBLK = Geo<NB>::NBLK;
-    __shared__ double s_G[WPB][KP * KP];
-    __shared__ int s_li[WPB][LIST_CAP];
-    __shared__ double s_lx[WPB][LIST_CAP];
+    constexpr int GPW = 64 / W;
+    __shared__ double s_G[WPB][GPW][W * W];
+    __shared__ int s_ord[WPB][80];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * WPB + w;
-    if (j >= a.p) return;
-    const int K = a.K;
-    double *G = s_G[w];
-    int *li = s_li[w];
-    double *lx = s_lx[w];
-    const bool valid = lane < K;
-    const int64_t off = (int64_t)j * a.pitch;
-
-    double q = valid ? a.Qfull[(size_t)j * KP + lane] : 0.0;
-    if (a.masked) {
-        d4 acc[NBLK];
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-        stream_line<0, 4>(a.vals + off, a.codes + off, (int)a.pitch, li, lx, lane,
-                          [&](int ng) { drain_syrk<NB>(li, lx, ng, a.R, K, acc, lane); });
-        acc_to_lds<NB>(acc, G, lane);
-        wave_sync();
-        if (valid) q -= G[K * KP + lane];                                               // :220-222 as complement
-        wave_sync();
-        for (int i = lane; i < KP * KP; i += WAVE) G[i] = a.RtR[i] - G[i];              // :218-219
-    } else {
-        for (int i = lane; i < KP * KP; i += WAVE) G[i] = a.RtR[i];                     // :234
+    const int grp = lane / W, l = lane & (W - 1);
+    const int slot = (blockIdx.x * WPB + w) * GPW + grp;
+    const int j = slot < a.p ? (a.gene_perm ? a.gene_perm[slot] : slot) : a.p;
+    const int K = a.K, KP = a.KP;
+    const bool gene = j < a.p, valid = gene && l < K;
+    double *Goff = s_G[w][grp];
+    const double *st = (a.stat && gene) ? a.stat + (size_t)j * a.stat_len : nullptr;
+    // XtX_j = R'R - complement (src/optimize.cpp:218-219), or the shared R'R (:234); zero diagonal in LDS
+    double Gll = 1.0;
+    for (int k = 0; k < K; ++k) {
+        double v = 0.0;
+        if (valid) {
+            v = a.RtR[k * KP + l];
+            if (st) v -= st[stat_index(k, l)];
+        }
+        if (k == l) { Gll = valid ? v : 1.0; v = 0.0; }
+        Goff[k * W + l] = v;
+    }
+    double q = 0.0, beta = 0.0;
+    if (valid) {
+        q = a.Qfull[(size_t)j * KP + l];                                                // :222,235 via level sums
+        if (st) q -= st[stat_index(K, l)];                                              // minus the held-out part
+        beta = a.C[(size_t)j * KP + l];
     }
     wave_sync();
-
-    double beta = valid ? a.C[(size_t)j * KP + lane] : 0.0;
     double g = 0.0;
     int sweeps = 0;
     if (a.mode == COL_CD) {                                                             // :228,246
-        sweeps = cd_solve(G, KP, K, q, beta, g, a.cd, (uint32_t)(a.gene_offset + j), lane);
-        if (valid) a.C[(size_t)j * KP + lane] = beta;
-    } else if (a.mode == COL_RIDGE) {                                                   // :224-226,237-240
-        if (valid) G[lane * KP + lane] += a.cd.lambda;
-        wave_sync();
-        double b = q;
-        const bool ok = chol_solve_lds(G, KP, K, b, lane);   // destroys G (rebuilt below if needed)
-        if (!ok && lane == 0) *a.fail = 1;
-        if (ok) beta = b;
-        if (valid) a.C[(size_t)j * KP + lane] = beta;
+        sweeps = cd_sweeps<W>(Goff, s_ord[w], K, Gll, q, beta, g, valid, a.cd, lane);
+        if (valid) a.C[(size_t)j * KP + l] = beta;
+        if (gene && l == 0) a.sweeps[j] = sweeps;
     }
-    if (lane == 0) a.sweeps[j] = sweeps;
     if (!a.checkpoint) return;
-
-    // ---- loss statistics with the updated column (src/utils.cpp:56-102 evaluated per gene) ----
-    if (a.mode == COL_RIDGE) {   // G was destroyed by the factorisation: rebuild it
-        wave_sync();
-        if (a.masked) {
-            d4 acc[NBLK];
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-            stream_line<0, 4>(a.vals + off, a.codes + off, (int)a.pitch, li, lx, lane,
-                              [&](int ng) { drain_syrk<NB>(li, lx, ng, a.R, K, acc, lane); });
-            acc_to_lds<NB>(acc, G, lane);
-            wave_sync();
-            for (int i = lane; i < KP * KP; i += WAVE) G[i] = a.RtR[i] - G[i];
-        } else {
-            for (int i = lane; i < KP * KP; i += WAVE) G[i] = a.RtR[i];
-        }
-        wave_sync();
-    }
-    // fresh g = q - G beta (the incrementally updated one carries the sweeps' round-off)
-    g = valid ? q : 0.0;
-    for (int m = 0; m < K; ++m) {
-        const double bm = readlane_d(beta, m);
-        if (bm != 0.0) g -= (valid ? G[m * KP + lane] : 0.0) * bm;
-    }
-    // sum_train (x - r'beta)^2 = yy - 2 beta'q + beta'G beta = yy - beta'(q + g)
-    const double bqg = wave_sum(valid ? beta * (q + g) : 0.0);
-    const double sb2 = wave_sum(valid ? beta * beta : 0.0);
-    const double sb1 = wave_sum(valid ? fabs(beta) : 0.0);
-    double te = 0.0;
-    if (a.masked) {   // test entries: explicit residuals on the compacted list
-        stream_line<1, 64>(a.vals + off, a.codes + off, (int)a.pitch, li, lx, lane, [&](int ng) {
-            for (int gi = 0; gi < ng; ++gi) {
-                const int e = li[64 * gi + lane];
-                const double xv = lx[64 * gi + lane];
-                const double *row = a.R + (size_t)(e < 0 ? 0 : e) * KP;
-                double dot = 0.0;
-                for (int k = 0; k < K; ++k) dot += row[k] * readlane_d(beta, k);
-                const double r = xv - dot;
-                te += e < 0 ? 0.0 : r * r;
-            }
-        });
-        te = wave_sum(te);
-    }
-    if (lane == 0) {
+    // ---- loss statistics with the (updated) column: sum_train (x - r'b)^2 = yy - 2 b'q + b'XtX b = yy - b'(q + g)
+    g = valid ? q - Gll * beta : 0.0;   // fresh g = q - XtX b (the swept one carries thousands of sweeps' round-off)
+    for (int m = 0; m < K; ++m) g -= Goff[m * W + l] * group_bcast<W>(beta, m, lane);
+    const double bqg = group_sum<W>(valid ? beta * (q + g) : 0.0, lane);
+    const double sb2 = group_sum<W>(valid ? beta * beta : 0.0, lane);
+    const double sb1 = group_sum<W>(valid ? fabs(beta) : 0.0, lane);
+    if (gene && l == 0) {
         a.sse_train[j] = a.yy[j] - bqg;
-        a.sse_test[j] = te;
         a.b2[j] = sb2;
         a.b1[j] = sb1;
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Kernel: batched stand-alone CD from (XtX, Xty) in global memory (insider_hip_strong_cd)
-// ---------------------------------------------------------------------------------------------
+// alpha == 0: per-gene ridge solve (src/optimize.cpp:224-226,237-240); one wave per gene
+struct RidgeArgs {
+    const double *stat;
+    int stat_len;
+    int p, K, KP;
+    const double *RtR, *Qfull;
+    double *C;
+    const double *yy;
+    double lambda;
+    int solve;        // 0: evaluate only
+    int checkpoint;
+    double *sse_train, *b2, *b1;
+    int *fail;
+};
+
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_ridge_cols(RidgeArgs a)
+{
+    __shared__ double s_A[WPB][64 * 64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * WPB + w;
+    if (j >= a.p) return;
+    const int K = a.K, KP = a.KP;
+    const bool valid = lane < K;
+    double *A = s_A[w];
+    const double *st = a.stat ? a.stat + (size_t)j * a.stat_len : nullptr;
+    auto load = [&]() {
+        for (int k = 0; k < K; ++k)
+            if (valid) A[k * K + lane] = a.RtR[k * KP + lane] - (st ? st[stat_index(k, lane)] : 0.0);
+        wave_sync();
+    };
+    load();
+    double q = 0.0, beta = 0.0;
+    if (valid) {
+        q = a.Qfull[(size_t)j * KP + lane] - (st ? st[stat_index(K, lane)] : 0.0);
+        beta = a.C[(size_t)j * KP + lane];
+    }
+    if (a.solve) {
+        if (valid) A[lane * K + lane] += a.lambda;
+        wave_sync();
+        double b = q;
+        const bool ok = chol_solve_lds(A, K, K, b, lane);
+        if (!ok) { if (lane == 0) *a.fail = 1; }
+        else beta = b;
+        if (valid) a.C[(size_t)j * KP + lane] = beta;
+        if (a.checkpoint) { wave_sync(); load(); }
+    }
+    if (!a.checkpoint) return;
+    double g = valid ? q : 0.0;
+    for (int m = 0; m < K; ++m) g -= (valid ? A[m * K + lane] : 0.0) * readlane_d(beta, m);
+    const double bqg = wave_sum(valid ? beta * (q + g) : 0.0);
+    const double sb2 = wave_sum(valid ? beta * beta : 0.0);
+    const double sb1 = wave_sum(valid ? fabs(beta) : 0.0);
+    if (lane == 0) {
+        a.sse_train[j] = a.yy[j] - bqg;
+        a.b2[j] = sb2;
+        a.b1[j] = sb1;
+    }
+}
+
+// sum over the test entries of one line of (x - f_e' beta)^2 (evaluate(), src/utils.cpp:67), one wave per line
 template <int WPB>
 __global__ void __launch_bounds__(WPB * 64)
-k_cd_batch(const double *__restrict__ XtX, const double *__restrict__ Xty, const double *__restrict__ wstart, int K,
-           int64_t nprob, CdParams cd, uint32_t unit0, double *__restrict__ beta_out, int *__restrict__ sweeps_out)
+k_test_sse(const double *__restrict__ vals, const uint8_t *__restrict__ codes, int64_t pitch, int lines,
+           const double *__restrict__ F /*[len][KP]*/, const double *__restrict__ B /*[lines][KP]*/, int K, int KP,
+           double *__restrict__ sse_test)
 {
-    __shared__ double s_G[WPB][64 * 64];
+    __shared__ int s_li[WPB][LIST_CAP];
+    __shared__ double s_lx[WPB][LIST_CAP];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * WPB + w;
-    if (b >= nprob) return;
-    double *G = s_G[w];
-    const double *src = XtX + (size_t)b * K * K;
-    for (int i = lane; i < K * K; i += WAVE) G[i] = src[i];
+    const int j = blockIdx.x * WPB + w;
+    if (j >= lines) return;
+    int *li = s_li[w];
+    double *lx = s_lx[w];
+    const double beta = lane < K ? B[(size_t)j * KP + lane] : 0.0;
+    const int64_t off = (int64_t)j * pitch;
+    double te = 0.0;
+    stream_line<1, 64>(vals + off, codes + off, (int)pitch, li, lx, lane, [&](int ng) {
+        for (int gi = 0; gi < ng; ++gi) {
+            const int e = li[64 * gi + lane];
+            const double xv = lx[64 * gi + lane];
+            const double *row = F + (size_t)(e < 0 ? 0 : e) * KP;
+            double dot = 0.0;
+            for (int k = 0; k < K; ++k) dot += row[k] * readlane_d(beta, k);
+            const double r = xv - dot;
+            te += e < 0 ? 0.0 : r * r;
+        }
+    });
+    te = wave_sum(te);
+    if (lane == 0) sse_test[j] = te;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel: batched stand-alone CD from dense (XtX, Xty) in global memory (insider_hip_strong_cd)
+// ---------------------------------------------------------------------------------------------
+template <int W, int WPB>
+__global__ void __launch_bounds__(WPB * 64)
+k_cd_batch(const double *__restrict__ XtX, const double *__restrict__ Xty, const double *__restrict__ wstart, int K,
+           int64_t nprob, CdParams cd, double *__restrict__ beta_out, int *__restrict__ sweeps_out)
+{
+    constexpr int GPW = 64 / W;
+    __shared__ double s_G[WPB][GPW][W * W];
+    __shared__ int s_ord[WPB][80];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane / W, l = lane & (W - 1);
+    const int64_t b = ((int64_t)blockIdx.x * WPB + w) * GPW + grp;
+    const bool prob = b < nprob, valid = prob && l < K;
+    double *Goff = s_G[w][grp];
+    double Gll = 1.0;
+    for (int k = 0; k < K; ++k) {
+        double v = valid ? XtX[(size_t)b * K * K + (size_t)k * K + l] : 0.0;
+        if (k == l) { Gll = valid ? v : 1.0; v = 0.0; }
+        Goff[k * W + l] = v;
+    }
     wave_sync();
-    const bool valid = lane < K;
-    const double q = valid ? Xty[(size_t)b * K + lane] : 0.0;
-    double beta = valid ? wstart[(size_t)b * K + lane] : 0.0, g;
-    const int sw = cd_solve(G, K, K, q, beta, g, cd, unit0 + (uint32_t)b, lane);
-    if (valid) beta_out[(size_t)b * K + lane] = beta;
-    if (lane == 0 && sweeps_out) sweeps_out[b] = sw;
+    const double q = valid ? Xty[(size_t)b * K + l] : 0.0;
+    double beta = valid ? wstart[(size_t)b * K + l] : 0.0, g;
+    const int sw = cd_sweeps<W>(Goff, s_ord[w], K, Gll, q, beta, g, valid, cd, lane);
+    if (valid) beta_out[(size_t)b * K + l] = beta;
+    if (prob && l == 0 && sweeps_out) sweeps_out[b] = sw;
 }
 
 // ---------------------------------------------------------------------------------------------

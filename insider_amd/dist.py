@@ -1,0 +1,105 @@
+"""Gene-axis sharding across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) as the exchange plumbing.
+
+Column subproblems are independent given the row factors (src/optimize.cpp:215-230), so rank g owns a contiguous
+gene slab of X / masks / C and runs the column pass on it alone.  The row update needs gene-global sums; every
+quantity entering a level's normal equations is linear in per-slab partial sums, so each rank reduces its slab to
+the L_i x (KP^2 + KP) per-level equations and ONE sum-all-reduce per covariate makes them global; every rank then
+solves the same tiny systems redundantly, which keeps the row factors bit-identical everywhere.  The loss needs one
+more all-reduce of 6 doubles per checkpoint (the collective BASELINE.json's north star names).
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def shard_range(p, rank, world):
+    """Contiguous gene slab [lo, hi) of rank `rank`: sizes differ by at most one gene."""
+    base, rem = divmod(int(p), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HostAllreduce:
+    """All-reduce of a HOST buffer given by address (CPU / gloo rehearsal of the exchange protocol)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.calls = []
+
+    def __call__(self, ptr, count):
+        import torch
+        arr = np.ctypeslib.as_array((C.c_double * count).from_address(ptr))
+        t = torch.from_numpy(arr)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.calls.append(count)
+
+
+class _DevBuf:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2,
+                                         "strides": None}
+
+
+class DeviceAllreduce:
+    """All-reduce of a DEVICE buffer given by address, through torch.distributed (RCCL).
+
+    Zero-copy when torch accepts the pointer through __cuda_array_interface__ (checked once by writing through the
+    alias); otherwise staged through a torch-owned buffer with device-to-device copies.
+    """
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.device = torch.device("cuda", device)
+        self.zero_copy = None
+        self.stage = None
+        self.hip = None
+        self.calls = []
+
+    def _alias(self, ptr, count):
+        return self.torch.as_tensor(_DevBuf(ptr, count), device=self.device)
+
+    def _probe(self, ptr, count):
+        torch = self.torch
+        try:
+            t = self._alias(ptr, count)
+            ok = t.data_ptr() == ptr and t.dtype == torch.float64 and t.numel() == count
+        except Exception:
+            ok = False
+        self.zero_copy = bool(ok)
+        if not ok:
+            self.hip = C.CDLL("libamdhip64.so")
+            self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def __call__(self, ptr, count):
+        torch = self.torch
+        if self.zero_copy is None:
+            self._probe(ptr, count)
+        if self.zero_copy:
+            t = self._alias(ptr, count)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.synchronize(self.device)
+        else:
+            if self.stage is None or self.stage.numel() < count:
+                self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device=self.device)
+            if self.hip.hipMemcpy(self.stage.data_ptr(), ptr, count * 8, 3) != 0:
+                raise RuntimeError("hipMemcpy D2D failed")
+            self.dist.all_reduce(self.stage[:count], op=self.dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.synchronize(self.device)
+            if self.hip.hipMemcpy(ptr, self.stage.data_ptr(), count * 8, 3) != 0:
+                raise RuntimeError("hipMemcpy D2D failed")
+        self.calls.append(count)
+
+
+def attach(ds, gene_offset, rank, world, device=None, group=None):
+    """Mark an InsiderData handle as one gene slab of a `world`-rank job and install the RCCL all-reduce."""
+    if world <= 1:
+        ds.set_shard(gene_offset, 0, 1, None)
+        return None
+    ar = DeviceAllreduce(device if device is not None else 0, group)
+    ds.set_shard(gene_offset, rank, world, ar)
+    return ar

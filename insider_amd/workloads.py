@@ -81,16 +81,38 @@ def interaction_indicator(confounder, interaction_idx):
     return np.asfortranarray(out)
 
 
-def holdout_masks(n, p, f, seed=MASK_SEED):
-    """Exactly floor(f*n*p) held-out entries, uniform without replacement (R/utils.R:88-100). No NA entries."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    tot = n * p
-    k = int(np.floor(tot * f))
+GENE_BLOCK = 1024   # X noise and hold-out masks are generated per block of genes from block-keyed streams
+
+
+def _block_counts(n, p, f, seed):
+    """How many of the floor(f*n*p) held-out entries fall in each gene block: sequential multivariate
+    hypergeometric draws, so that (counts, then uniform choice inside each block) is exactly a uniform sample
+    without replacement of the whole matrix (R/utils.R:88-100) while every block can be generated on its own."""
+    rng = np.random.Generator(np.random.PCG64([seed, 0]))
+    nblk = (p + GENE_BLOCK - 1) // GENE_BLOCK
+    sizes = np.array([n * (min((b + 1) * GENE_BLOCK, p) - b * GENE_BLOCK) for b in range(nblk)], dtype=np.int64)
+    k = int(np.floor(n * p * f))
+    counts = np.zeros(nblk, dtype=np.int64)
+    remaining_total, remaining_k = int(sizes.sum()), k
+    for b in range(nblk):
+        if remaining_k == 0:
+            break
+        good, bad = int(sizes[b]), remaining_total - int(sizes[b])
+        counts[b] = rng.hypergeometric(good, bad, remaining_k) if bad > 0 else remaining_k
+        remaining_total -= good
+        remaining_k -= int(counts[b])
+    return counts
+
+
+def _block_test_mask(n, width, k, seed, b):
+    """Exactly k test entries, uniform without replacement, inside an n x width block (Fortran order)."""
+    rng = np.random.Generator(np.random.PCG64([seed, 2, b]))
+    tot = n * width
     test = np.zeros(tot, dtype=np.uint8)
     if k > 0:
-        if tot <= 50_000_000:
+        if tot <= 2_000_000:
             test[rng.choice(tot, size=k, replace=False)] = 1
-        else:  # random keys + k-th smallest: same distribution, O(tot) memory in float32
+        else:  # random keys + k-th smallest: same distribution
             keys = rng.random(tot, dtype=np.float32)
             thr = np.partition(keys, k - 1)[k - 1]
             sel = np.flatnonzero(keys <= thr)
@@ -98,9 +120,38 @@ def holdout_masks(n, p, f, seed=MASK_SEED):
                 tie = np.flatnonzero(keys[sel] == thr)
                 sel = np.delete(sel, tie[: sel.size - k])
             test[sel] = 1
-    test = test.reshape((n, p), order="F")
-    train = (1 - test).astype(np.uint8)
-    return np.asfortranarray(train), np.asfortranarray(test)
+    return test.reshape((n, width), order="F")
+
+
+def holdout_masks(n, p, f, seed=MASK_SEED, gene_range=None):
+    """Exactly floor(f*n*p) held-out entries over the WHOLE n x p matrix, uniform without replacement
+    (R/utils.R:88-100); returns the (train, test) masks of the requested gene slab. No NA entries."""
+    lo, hi = gene_range if gene_range is not None else (0, p)
+    counts = _block_counts(n, p, f, seed)
+    test = np.zeros((n, hi - lo), dtype=np.uint8, order="F")
+    blocks = range(lo // GENE_BLOCK, (hi + GENE_BLOCK - 1) // GENE_BLOCK)
+
+    def one(b):
+        b0, b1 = b * GENE_BLOCK, min((b + 1) * GENE_BLOCK, p)
+        m = _block_test_mask(n, b1 - b0, int(counts[b]), seed, b)
+        s0, s1 = max(b0, lo), min(b1, hi)
+        test[:, s0 - lo:s1 - lo] = m[:, s0 - b0:s1 - b0]
+
+    _pmap(one, blocks)
+    train = (1 - test).astype(np.uint8, order="F")
+    return train, test
+
+
+def _pmap(fn, items, workers=None):
+    items = list(items)
+    if len(items) <= 1:
+        for it in items:
+            fn(it)
+        return
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers or min(16, os.cpu_count() or 1)) as ex:
+        list(ex.map(fn, items))
 
 
 def init_factors(n_levels, K, p, seed=INIT_SEED):
@@ -142,22 +193,23 @@ def make(name=None, n=None, p=None, level_counts=None, interaction_idx=None, K=N
     lo, hi = gene_range if gene_range is not None else (0, p)
     # noise is drawn per 1024-gene block from a block-keyed stream so any slab reproduces the full matrix
     X = np.empty((n, hi - lo), dtype=np.float64, order="F")
-    blk = 1024
-    for b0 in range((lo // blk) * blk, hi, blk):
-        brng = np.random.Generator(np.random.PCG64([data_seed, 1, b0 // blk]))
-        b1 = min(b0 + blk, p)
-        noise = brng.standard_normal((n, b1 - b0))
+    blk = GENE_BLOCK
+
+    def one(b):
+        b0, b1 = b * blk, min((b + 1) * blk, p)
+        brng = np.random.Generator(np.random.PCG64([data_seed, 1, b]))
+        noise = brng.standard_normal((b1 - b0, n)).T      # Fortran-ordered n x width block
         s0, s1 = max(b0, lo), min(b1, hi)
         X[:, s0 - lo:s1 - lo] = Rstar @ Cstar[:, s0:s1] + noise[:, s0 - b0:s1 - b0]
+
+    _pmap(one, range(lo // blk, (hi + blk - 1) // blk))
     if tuning == 1 and f > 0:
-        Mtr, Mte = holdout_masks(n, p, f, mask_seed)
+        Mtr, Mte = holdout_masks(n, p, f, mask_seed, gene_range=(lo, hi))
     else:
-        Mtr = np.ones((n, p), dtype=np.uint8, order="F")
-        Mte = np.zeros((n, p), dtype=np.uint8, order="F")
+        Mtr = np.ones((n, hi - lo), dtype=np.uint8, order="F")
+        Mte = np.zeros((n, hi - lo), dtype=np.uint8, order="F")
     A0, C0 = init_factors(n_levels, K, p, init_seed)
     if gene_range is not None:
-        Mtr = np.asfortranarray(Mtr[:, lo:hi])
-        Mte = np.asfortranarray(Mte[:, lo:hi])
         C0 = np.asfortranarray(C0[:, lo:hi])
     return Workload(name=name, X=X, levels=levels, n_levels=n_levels, M_train=Mtr, M_test=Mte, K=K, lam=lam,
                     alpha=alpha, tuning=tuning, A0=A0, C0=C0)

@@ -151,13 +151,12 @@ static double sub_loss(const double *resid, int m, const double *beta, int K, do
 
 /* Sweep order over the active set: mode 0 = ascending hashed key
  * (include/insider_perm.h), mode 1 = ascending index (cyclic).              */
-static void sweep_order(const int *inc, int ninc, uint64_t seed, uint32_t unit, uint32_t iter,
-                        uint32_t sweep, int mode, int *ord)
+static void sweep_order(const int *inc, int ninc, uint64_t seed, uint32_t iter, uint32_t sweep, int mode, int *ord)
 {
     for (int i = 0; i < ninc; i++) ord[i] = inc[i];
     if (mode != 0) return;
     uint32_t keys[64];
-    uint32_t base = insider_perm_base(seed, unit, iter, sweep);
+    uint32_t base = insider_perm_base(seed, iter, sweep);
     for (int i = 0; i < ninc; i++) keys[i] = insider_perm_key(base, (uint32_t)inc[i]);
     for (int i = 1; i < ninc; i++) { /* insertion sort, ninc <= 64 */
         uint32_t kk = keys[i]; int v = ord[i]; int j = i - 1;
@@ -203,7 +202,7 @@ int oracle_strong_cd(const double *X, const double *y, int m, int K, const doubl
         for (int k = 0; k < K; k++) { if (active[k]) inc[ninc++] = k; else ex[nex++] = k; }
         do { /* :86-114 */
             pre_loss = iter_loss;
-            sweep_order(inc, ninc, seed, unit, iter, sweep, order_mode, ord);
+            sweep_order(inc, ninc, seed, iter, sweep, order_mode, ord);
             sweep++;
             for (int t = 0; t < ninc; t++) {
                 int k = ord[t];

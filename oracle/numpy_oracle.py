@@ -23,8 +23,8 @@ def h32(x):
     return x
 
 
-def perm_base(seed, unit, it, sweep):
-    b = h32((seed & M32) ^ ((0x9E3779B9 * unit) & M32))
+def perm_base(seed, it, sweep):
+    b = h32((seed & M32) ^ 0x9E3779B9)
     b = h32(b ^ ((seed >> 32) & M32) ^ ((0x85EBCA6B * it) & M32))
     b = h32((b + 0xC2B2AE35 * sweep) & M32)
     return b
@@ -37,7 +37,7 @@ def perm_key(base, l):
 def sweep_order(inc, seed, unit, it, sweep, order_mode):
     if order_mode != 0:
         return list(inc)
-    base = perm_base(seed, unit, it, sweep)
+    base = perm_base(seed, it, sweep)
     return sorted(inc, key=lambda l: perm_key(base, int(l)))
 
 

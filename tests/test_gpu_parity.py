@@ -114,7 +114,7 @@ def test_strong_cd_matches_oracle(oracle, K, lam, alpha, tol):
         Xs.append(X); ys.append(y); Gs.append(X.T @ X); qs.append(X.T @ y); ws.append(rng.standard_normal(K) * 0.1)
     for mode in (0, 1):
         beta, sw = api.strong_coordinate_descent(None, None, np.array(ws), lam, alpha, np.array(Gs), np.array(qs),
-                                                 tol=tol, seed=99, unit=1000, it=7, order_mode=mode,
+                                                 tol=tol, seed=99, it=7, order_mode=mode,
                                                  return_sweeps=True)
         same_sweeps = 0
         for b in range(B):
