@@ -165,14 +165,16 @@ def optimize(X, levels, n_levels, A_list, Cmat, M_train, M_test, lam1, lam2, alp
     rows = C.c_int()
     iters = C.c_int()
     sw = C.c_int64()
+    phases = np.zeros(3)
     rc = lib().oracle_optimize(_p(X), C.c_int(n), C.c_int(p), _p(levels, C.c_int32), C.c_int(c),
                                _p(n_levels, C.c_int32), Aptrs, _p(Cout), _p(Mtr, C.c_uint8), _p(Mte, C.c_uint8),
                                C.c_int(K), C.c_double(lam1), C.c_double(lam2), C.c_double(alpha), C.c_int(tuning),
                                C.c_double(global_tol), C.c_double(sub_tol), C.c_uint32(max_iter), C.c_uint64(seed),
                                C.c_int(order_mode), C.c_int(max_sweeps), C.c_int(row_threads), C.c_int(col_threads),
                                C.byref(tr), C.byref(te), C.byref(lo), _p(traj), C.c_int(traj_cap), C.byref(rows),
-                               C.byref(iters), C.byref(sw))
+                               C.byref(iters), C.byref(sw), _p(phases))
     if rc:
         raise RuntimeError(f"oracle_optimize failed rc={rc}")
     return dict(row_matrices=A, column_factor=Cout, train_rmse=tr.value, test_rmse=te.value, loss=lo.value,
-                traj=traj[:rows.value].copy(), iters=iters.value, total_sweeps=sw.value)
+                traj=traj[:rows.value].copy(), iters=iters.value, total_sweeps=sw.value,
+                phase_seconds=dict(row=phases[0], col=phases[1], residual_eval=phases[2]))

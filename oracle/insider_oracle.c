@@ -51,6 +51,15 @@
 #define ORACLE_ERR_SOLVE 2
 #define ORACLE_ERR_ALLOC 3
 
+static double now_s(void)
+{
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
 /* ------------------------------------------------------------------------- */
 /* small dense helpers                                                        */
 /* ------------------------------------------------------------------------- */
@@ -562,8 +571,9 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
                     double global_tol, double sub_tol, uint32_t max_iter, uint64_t seed, int order_mode,
                     int max_sweeps, int row_threads, int col_threads, double *out_train_rmse,
                     double *out_test_rmse, double *out_loss, double *traj, int traj_cap, int *out_traj_rows,
-                    int *out_iters, int64_t *out_total_sweeps)
+                    int *out_iters, int64_t *out_total_sweeps, double *phase_seconds /* optional: {row, col, residual+eval} */)
 {
+    double ph[3] = {0.0, 0.0, 0.0}, tp;
     if (tuning != 0 && tuning != 1) return ORACLE_ERR_ARG;
     if (K < 1 || K > 64 || c < 1) return ORACLE_ERR_ARG;
     for (int i = 0; i < c; i++)
@@ -587,6 +597,7 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
                 R[r + (size_t)k * n] += A[i][(levels[r + (size_t)i * n] - 1) + (size_t)k * n_levels[i]];
 
     double sum_residual, train_rmse, test_rmse, loss, pre_loss, delta_loss, decay = 1.0, comps[4];
+    tp = now_s();
     residual_from_scratch(X, R, C, resid, n, p, K, col_threads);                           /* :320-321 */
     evaluate(resid, Mtr, Mte, tuning, n, p, &sum_residual, &train_rmse, &test_rmse, col_threads); /* :322 */
     loss = global_loss(A, n_levels, c, C, p, K, lambda1, lambda2, alpha, sum_residual, comps);    /* :323 */
@@ -597,8 +608,10 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
         trows++;
     }
 
+    ph[2] += now_s() - tp;
     uint32_t iter = 0;
     while (iter <= max_iter) {                                                              /* :325 */
+        tp = now_s();
         /* :332 gram = C C' */
         for (int b = 0; b < K; b++)
             for (int a = 0; a < K; a++) {
@@ -615,6 +628,8 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
                 residual_add_cov(resid, A[i], n_levels[i], lev, C, -1.0, n, p, K, col_threads);
         }
         if (rc != ORACLE_OK) break;
+        ph[0] += now_s() - tp;
+        tp = now_s();
         /* :365-369 */
         for (size_t e = 0; e < (size_t)n * K; e++) R[e] = 0.0;
         for (int i = 0; i < c; i++)
@@ -627,6 +642,8 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
                                  order_mode, max_sweeps, col_threads, 0, &sw);
         sweeps_total += sw;
         if (rc != ORACLE_OK) break;
+        ph[1] += now_s() - tp;
+        tp = now_s();
         residual_from_scratch(X, R, C, resid, n, p, K, col_threads);                       /* :377-378 */
 
         if (iter % 10 == 0) {                                                               /* :381-408 */
@@ -647,10 +664,12 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
                 t[5] = comps[2]; t[6] = comps[3]; t[7] = loss; t[8] = delta_loss; t[9] = decay;
                 trows++;
             }
-            if ((pre_loss - loss) / pre_loss < global_tol) break;                           /* :405-407 */
+            if ((pre_loss - loss) / pre_loss < global_tol) { ph[2] += now_s() - tp; break; }   /* :405-407 */
         }
+        ph[2] += now_s() - tp;
         iter++;
     }
+    if (phase_seconds) { phase_seconds[0] = ph[0]; phase_seconds[1] = ph[1]; phase_seconds[2] = ph[2]; }
     free(R); free(resid); free(gram);
     if (out_train_rmse) *out_train_rmse = train_rmse;
     if (out_test_rmse) *out_test_rmse = test_rmse;

@@ -1,0 +1,124 @@
+"""Gene-axis sharding rehearsed on the CPU with gloo, world_size 2.
+
+What runs here is the exchange protocol of insider_amd/dist.py and the algebra the HIP driver shards by: every term of
+a level's ridge normal equations (src/optimize.cpp:161-175) is a sum over genes, so each rank reduces its gene slab to
+the L_i x (K^2 + K) per-level equations and ONE sum-all-reduce per covariate makes them global; the loss needs one
+all-reduce of {SSE_train, SSE_test, sum c^2, sum |c|, #train, #test}.  The slab partials are formed in numpy exactly
+the way the kernels form them (complement statistics over held-out entries + per-level sums of X), and the reduced
+result must equal the CPU oracle's update on the UNSHARDED problem.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from insider_amd import dist as idist
+from insider_amd import workloads
+
+
+def test_shard_range_partitions():
+    for p, world in ((50000, 8), (7, 3), (5, 8), (200000, 4)):
+        spans = [idist.shard_range(p, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == p
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _slab_level_equations(w, A, Cm, cov, lo, hi):
+    """This rank's share of covariate `cov`'s per-level equations, formed like the kernels do."""
+    X, M, lev = w.X[:, lo:hi], w.M_train[:, lo:hi], w.levels
+    Cs = Cm[:, lo:hi]
+    K, L = Cm.shape[0], int(w.n_levels[cov])
+    CCt = Cs @ Cs.T                                   # this slab's part of C C'
+    eq = np.zeros((L, K * K + K))
+    s_all = sum(A[m][lev[:, m] - 1, :] for m in range(lev.shape[1]) if m != cov)     # s_r = sum_{m != cov} A_m[level]
+    for l in range(L):
+        members = np.flatnonzero(lev[:, cov] == l + 1)
+        XtX = len(members) * CCt
+        Xty = Cs @ X[members, :].sum(axis=0)          # (S_i C')[l]: per-level sum of X rows, then times C'
+        for r in members:
+            held = M[r, :] == 0
+            Hc = Cs[:, held] @ Cs[:, held].T          # complement Gram
+            bc = Cs[:, held] @ X[r, held]             # complement XtY
+            XtX -= Hc
+            Xty += -bc - CCt @ s_all[r] + Hc @ s_all[r]
+        eq[l, :K * K] = XtX.ravel()
+        eq[l, K * K:] = Xty
+    return eq
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = workloads.small(n=60, p=90, level_counts=(5, 4), K=4, f=0.15, seed=11, with_na=True)
+        rng = np.random.default_rng(3)
+        A = [rng.standard_normal(a.shape) * 0.3 for a in w.A0]
+        Cm = rng.standard_normal(w.C0.shape) * 0.3
+        lo, hi = idist.shard_range(w.p, rank, world)
+        ar = idist.HostAllreduce()
+        K, lam = w.K, 1.7
+        new_A = [a.copy() for a in A]
+        for cov in range(w.levels.shape[1]):          # Gauss-Seidel over covariates: one all-reduce each
+            eq = np.ascontiguousarray(_slab_level_equations(w, new_A, Cm, cov, lo, hi))
+            ar(eq.ctypes.data, eq.size)               # the callback signature the C ABI uses: (pointer, count)
+            for l in range(eq.shape[0]):
+                XtX = eq[l, :K * K].reshape(K, K) + lam * np.eye(K)
+                new_A[cov][l] = np.linalg.solve(XtX, eq[l, K * K:])
+        # loss terms: slab sums + one all-reduce of 6 doubles
+        R = sum(new_A[m][w.levels[:, m] - 1, :] for m in range(w.levels.shape[1]))
+        resid = w.X[:, lo:hi] - R @ Cm[:, lo:hi]
+        tr, te = w.M_train[:, lo:hi] != 0, w.M_test[:, lo:hi] != 0
+        buf = np.array([np.sum(resid[tr] ** 2), np.sum(resid[te] ** 2), np.sum(Cm[:, lo:hi] ** 2),
+                        np.sum(np.abs(Cm[:, lo:hi])), tr.sum(), te.sum()], dtype=np.float64)
+        ar(buf.ctypes.data, buf.size)
+        q.put((rank, [a.copy() for a in new_A], buf.copy(), list(ar.calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_row_update_and_loss_match_unsharded(oracle):
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # both ranks end with bit-identical row factors (they solve the same reduced systems)
+    for a0, a1 in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a0, a1)
+    assert np.array_equal(outs[0][2], outs[1][2])
+    # ... equal to the oracle's row updates on the unsharded problem (reference formulation: Gauss-Seidel residual)
+    w = workloads.small(n=60, p=90, level_counts=(5, 4), K=4, f=0.15, seed=11, with_na=True)
+    rng = np.random.default_rng(3)
+    A = [rng.standard_normal(a.shape) * 0.3 for a in w.A0]
+    Cm = rng.standard_normal(w.C0.shape) * 0.3
+    gram = Cm @ Cm.T
+    ref_A = [a.copy() for a in A]
+    resid = w.X - sum(ref_A[m][w.levels[:, m] - 1, :] for m in range(2)) @ Cm
+    for cov in range(2):
+        resid = resid + ref_A[cov][w.levels[:, cov] - 1, :] @ Cm                       # src/optimize.cpp:338
+        ref_A[cov] = oracle.optimize_row(resid, w.M_train, ref_A[cov], Cm, w.levels[:, cov], gram, 1.7, 1)
+        resid = resid - ref_A[cov][w.levels[:, cov] - 1, :] @ Cm                       # :354
+    for got, ref in zip(outs[0][1], ref_A):
+        np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12)
+    R = sum(ref_A[m][w.levels[:, m] - 1, :] for m in range(2))
+    full = w.X - R @ Cm
+    exp = [np.sum(full[w.M_train != 0] ** 2), np.sum(full[w.M_test != 0] ** 2), np.sum(Cm ** 2), np.sum(np.abs(Cm)),
+           np.count_nonzero(w.M_train), np.count_nonzero(w.M_test)]
+    np.testing.assert_allclose(outs[0][2], exp, rtol=1e-10)
+    # exchange volume: one all-reduce per covariate of L_i (K^2 + K) doubles, one of 6 for the loss
+    assert outs[0][3] == [5 * (16 + 4), 4 * (16 + 4), 6]
