@@ -156,7 +156,7 @@ def main():
                                    f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}",
                        "genes_per_gpu": p_loc, "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
                        "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_line_stats (masked Gram/XtY complement statistics, column side)",
+            "roofline": {"kernel": "k_list_stats (masked Gram/XtY complement statistics over the held-out lists, column side)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],

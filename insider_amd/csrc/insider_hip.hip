@@ -78,6 +78,12 @@ struct insider_hip_handle {
     int max_chunks = 0, max_L = 0;
     double *S = nullptr, *yy_train = nullptr, *yy_all = nullptr;
     double cnt_train = 0, cnt_test = 0;
+    bool no_na = false;     // every entry is train or test: held-out == test
+    // held-out lists (element index, value) of every gene (col) and of every sample (row); padded to LIST_ALIGN
+    uint32_t *col_ptr = nullptr, *row_ptr = nullptr;
+    int *col_idx = nullptr, *row_idx = nullptr;
+    double *col_val = nullptr, *row_val = nullptr;
+    uint64_t col_entries = 0, row_entries = 0;
     // factor-dependent workspace for the current K
     int K = 0, NB = 0, KP = 0, nseg = 1, seg_len = 0;
     double *Astack = nullptr, *R = nullptr, *C = nullptr, *RtR = nullptr, *CCt = nullptr, *Qfull = nullptr, *SC = nullptr;
@@ -100,7 +106,7 @@ struct insider_hip_handle {
     insider_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
     // options
-    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0;
+    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0, dbg_skip_drain = 0;
     // profile of the last optimize()
     std::vector<hipEvent_t> ev_col, ev_row, ev_cd, ev_test;
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -140,11 +146,12 @@ int ensure_workspace(insider_hip_handle *h, int K)
     h->NB = NB;
     h->KP = KP;
     // row-side segmentation: enough work items to fill 256 CUs even for few samples
-    int nseg = (int)std::min<int64_t>(std::max<int64_t>(1, cdiv(8192, h->n)), std::max<int64_t>(1, h->ldp / 1024));
-    int seg_len = (int)round_up(cdiv(h->ldp, nseg), CHUNK);
-    nseg = cdiv(h->ldp, seg_len);
+    // enough work items to fill 256 CUs even for few samples: split long lists into up to 64 segments
+    const int64_t avg_batches = (int64_t)(h->row_entries / (uint64_t)LIST_ALIGN / (uint64_t)std::max<int64_t>(h->n, 1));
+    int nseg = (int)std::min<int64_t>(std::max<int64_t>(1, cdiv(8192, h->n)), std::max<int64_t>(1, avg_batches / 16));
+    nseg = std::min(nseg, 64);
     h->nseg = nseg;
-    h->seg_len = seg_len;
+    h->seg_len = 0;
     h->gram_blocks_p = cdiv(h->p, 256);
     h->gram_blocks_n = cdiv(h->n, 256);
     h->sc_blocks = cdiv(h->p, 256);
@@ -204,12 +211,16 @@ int ensure_workspace(insider_hip_handle *h, int K)
         default: { constexpr int NB_ = 4; constexpr int WPB_ = 1; __VA_ARGS__; } break;  \
     }
 
-int launch_line_stats(insider_hip_handle *h, const double *vals, const uint8_t *codes, int64_t pitch, int units,
-                      int nseg, int seg_len, const double *F, double *stat)
+int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *F, double *stat)
 {
+    const int units = cols ? (int)h->p : (int)h->n;
+    const int64_t f_rows = cols ? h->n : h->p;
+    const uint32_t *ptr = cols ? h->col_ptr : h->row_ptr;
+    const int *lidx = cols ? h->col_idx : h->row_idx;
+    const double *lval = cols ? h->col_val : h->row_val;
     const int64_t items = (int64_t)units * nseg;
-    NB_DISPATCH(h->NB, hipLaunchKernelGGL((k_line_stats<NB_, WPB_>), dim3(cdiv(items, WPB_)), dim3(WPB_ * 64), 0,
-                                           h->stream, vals, codes, pitch, units, nseg, seg_len, F, h->K, stat));
+    NB_DISPATCH(h->NB, hipLaunchKernelGGL((k_list_stats<NB_, WPB_>), dim3(cdiv(items, WPB_)), dim3(WPB_ * 64), 0,
+                                           h->stream, ptr, lidx, lval, units, nseg, F, f_rows, stat));
     KCHECK();
     return INSIDER_OK;
 }
@@ -285,7 +296,7 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
-    rc = launch_line_stats(h, h->X, h->codes, h->ldn, (int)h->p, 1, (int)h->ldn, h->R, h->stat_col);
+    rc = launch_list_stats(h, true, 1, h->R, h->stat_col);
     if (rc) return rc;
     return t.end(h, h->ev_col);
 }
@@ -315,6 +326,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.sse_train = h->sse_train;
         a.b2 = h->b2;
         a.b1 = h->b1;
+        a.sse_test = h->sse_test;
+        a.test_from_stats = masked && h->no_na;
         a.fail = h->failflag;
         hipLaunchKernelGGL((k_ridge_cols<1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
         KCHECK();
@@ -340,6 +353,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.sse_train = h->sse_train;
         a.b2 = h->b2;
         a.b1 = h->b1;
+        a.sse_test = h->sse_test;
+        a.test_from_stats = masked && h->no_na;
         a.sweeps = h->sweeps;
         a.gene_perm = (solve && h->have_perm) ? h->gene_perm : nullptr;
         if (h->K <= 16) hipLaunchKernelGGL((k_cd_cols<16, 4>), dim3(cdiv(h->p, 16)), dim3(256), 0, h->stream, a);
@@ -370,6 +385,7 @@ int launch_test_sse(insider_hip_handle *h, int masked, bool timed)
         HIPCHECK(hipMemsetAsync(h->sse_test, 0, (size_t)h->p * sizeof(double), h->stream));
         return INSIDER_OK;
     }
+    if (h->no_na) return INSIDER_OK;   // the column kernel derived the test residuals from the statistics
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
@@ -385,7 +401,7 @@ int launch_row_stats(insider_hip_handle *h, bool timed)
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
-    rc = launch_line_stats(h, h->Xt, h->codes_t, h->ldp, (int)h->n, h->nseg, h->seg_len, h->C, h->stat);
+    rc = launch_list_stats(h, false, h->nseg, h->C, h->stat);
     if (rc) return rc;
     return t.end(h, h->ev_row);
 }
@@ -522,7 +538,8 @@ void insider_hip_destroy(insider_hip_handle *h)
     clear_events(h);
     free_workspace(h);
     void *ptrs[] = {h->X, h->Xt, h->codes, h->codes_t, h->lev, h->lvl_off_d, h->members_all, h->lvl_ptr_all,
-                    h->lvl_count_all, h->S, h->yy_train, h->yy_all};
+                    h->lvl_count_all, h->S, h->yy_train, h->yy_all, h->col_ptr, h->row_ptr, h->col_idx, h->row_idx,
+                    h->col_val, h->row_val};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &ct : h->cov) {
         if (ct.chunk_level) (void)hipFree(ct.chunk_level);
@@ -676,10 +693,49 @@ int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *lev
         CH(hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
         CH(hipStreamSynchronize(h->stream));
         (void)hipFree(cnt);
-        // pad elements of each line are coded "train" with x = 0: remove them from the count
         h->cnt_train = (double)hc[0];
         h->cnt_test = (double)hc[1];
+        h->no_na = hc[0] + hc[1] == (unsigned long long)n * (unsigned long long)p;
     }
+    // ---- held-out lists of both sides (the masks never change: built once) -------------------------------------------
+    if (n >= LIST_PAD || p >= LIST_PAD) { insider_hip_destroy(h); return fail(INSIDER_ERR_UNSUPPORTED, "n and p must be below 2^23"); }
+    for (int side = 0; side < 2; ++side) {
+        const bool cols = side == 0;
+        const int lines = cols ? (int)p : (int)n, len = cols ? (int)n : (int)p;
+        const double *vals = cols ? h->X : h->Xt;
+        const uint8_t *cds = cols ? h->codes : h->codes_t;
+        const int64_t pitch = cols ? h->ldn : h->ldp;
+        int *cnt_d = nullptr;
+        CR(dmalloc(&cnt_d, (size_t)lines));
+        hipLaunchKernelGGL(k_count_heldout, dim3(cdiv(lines, 4)), dim3(256), 0, h->stream, cds, pitch, len, lines, cnt_d);
+        CH(hipGetLastError());
+        std::vector<int> cnt(lines);
+        CH(hipMemcpyAsync(cnt.data(), cnt_d, (size_t)lines * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        CH(hipStreamSynchronize(h->stream));
+        (void)hipFree(cnt_d);
+        std::vector<uint32_t> ptr((size_t)lines + 1);
+        uint64_t tot = 0;
+        for (int i = 0; i < lines; ++i) { ptr[i] = (uint32_t)tot; tot += (uint64_t)round_up(cnt[i], LIST_ALIGN); }
+        ptr[lines] = (uint32_t)tot;
+        if (tot >= (1ull << 32)) { insider_hip_destroy(h); return fail(INSIDER_ERR_UNSUPPORTED, "more than 2^32 held-out entries"); }
+        uint32_t *&dptr = cols ? h->col_ptr : h->row_ptr;
+        int *&didx = cols ? h->col_idx : h->row_idx;
+        double *&dval = cols ? h->col_val : h->row_val;
+        (cols ? h->col_entries : h->row_entries) = tot;
+        CR(dmalloc(&dptr, ptr.size()));
+        CR(dmalloc(&didx, (size_t)tot + LIST_BLOCK));
+        CR(dmalloc(&dval, (size_t)tot + LIST_BLOCK));
+        CH(hipMemcpyAsync(dptr, ptr.data(), ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_fill_lists, dim3(cdiv(lines, 4)), dim3(256), 0, h->stream, vals, cds, pitch, len, lines,
+                           (const uint32_t *)dptr, didx, dval);
+        CH(hipGetLastError());
+        CH(hipStreamSynchronize(h->stream));
+    }
+    // the transposed copies were only needed to build the row-side lists
+    (void)hipFree(h->Xt);
+    (void)hipFree(h->codes_t);
+    h->Xt = nullptr;
+    h->codes_t = nullptr;
 #undef CR
 #undef CH
     *out = h;
@@ -707,6 +763,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "order_mode") h->order_mode = (int)value;
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
+    else if (s == "dbg_skip_drain") h->dbg_skip_drain = (int)value;   // diagnostics: time the streaming/compaction alone
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
 }
@@ -955,16 +1012,16 @@ static int masked_gram_common(insider_hip_handle *h, bool cols, const double *Fh
     if ((rc = launch_gram(h, F, flen, full))) return rc;
     double *stat = nullptr, *qf = nullptr, *Gd = nullptr, *qd = nullptr;
     const int NBLK = h->NB * (h->NB + 1) / 2, STAT = NBLK * 256;
-    const int nseg = cols ? 1 : h->nseg, seg_len = cols ? (int)h->ldn : h->seg_len;
+    const int nseg = cols ? 1 : h->nseg;
     if ((rc = dmalloc(&stat, (size_t)nseg * units * STAT)) || (rc = dmalloc(&qf, (size_t)units * KP)) ||
         (rc = dmalloc(&Gd, (size_t)units * K * K)) || (rc = dmalloc(&qd, (size_t)units * K)))
         return rc;
-    const double *vals = cols ? h->X : h->Xt;
-    const uint8_t *codes = cols ? h->codes : h->codes_t;
-    const int64_t pitch = cols ? h->ldn : h->ldp;
-    if ((rc = launch_line_stats(h, vals, codes, pitch, (int)units, nseg, seg_len, F, stat))) return rc;
-    hipLaunchKernelGGL(k_line_dense_xty, dim3((unsigned)units), dim3(64), 0, h->stream, vals, pitch, (int)flen,
-                       (const double *)F, K, KP, qf);
+    if ((rc = launch_list_stats(h, cols, nseg, F, stat))) return rc;
+    // dense X'F over all entries from the gene-major copy (rows: strided reads; stand-alone API only)
+    if (cols) hipLaunchKernelGGL(k_line_dense_xty, dim3((unsigned)units), dim3(64), 0, h->stream, (const double *)h->X,
+                                 h->ldn, (int)flen, (const double *)F, K, KP, qf);
+    else hipLaunchKernelGGL(k_row_dense_xty, dim3((unsigned)units), dim3(64), 0, h->stream, (const double *)h->X, h->ldn,
+                            (int)flen, (const double *)F, K, KP, qf);
     KCHECK();
     NB_DISPATCH(h->NB, {
         (void)WPB_;

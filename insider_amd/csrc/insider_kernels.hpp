@@ -28,7 +28,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int WAVE = 64;
-constexpr int LIST_CAP = 256;   // held-out ring entries per wave (>= 2 * 128)
+constexpr int LIST_CAP = 512;   // held-out ring entries per wave (>= 2 * 128)
 constexpr int CHUNK = 128;      // elements per streaming step (2 per lane); line pitches are multiples of it
 
 constexpr int CODE_TRAIN = 1;   // bit 0 of a mask code: entry is in the train set
@@ -39,6 +39,7 @@ struct Geo {
     static constexpr int KP = 16 * NB;               // padded row length of factor rows (>= K + 1)
     static constexpr int NBLK = NB * (NB + 1) / 2;   // lower-triangular 16x16 blocks
     static constexpr int STAT = NBLK * 256;          // doubles per unit of block-stored statistics
+    static constexpr int ROW_BYTES = KP * 8;         // bytes per padded factor row
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -80,29 +81,52 @@ __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane
 // streaming + compaction of one line
 // ---------------------------------------------------------------------------------------------
 // Streams `pitch` (multiple of CHUNK) elements of one line, appends those whose code passes the filter to the
-// wave's LDS ring (element index + value) in ascending element order and calls drain(ngroups) whenever the ring
-// could overflow, and once at the end after padding to a multiple of GROUP with (-1, 0.0) dummies.
+// wave's LDS ring (element index * TAG_MUL, value) in ascending element order and calls drain(ngroups) whenever
+// the ring could overflow, and once at the end after padding to a multiple of GROUP with (-1, 0.0) dummies.
 //   FILTER 0: held out of the train set (code & CODE_TRAIN) == 0      FILTER 1: test entries (code & CODE_TEST)
-template <int FILTER, int GROUP, class Drain>
+template <int FILTER, int GROUP, int TAG_MUL, class Drain>
 __device__ __forceinline__ void stream_line(const double *__restrict__ vals, const uint8_t *__restrict__ codes,
                                             int pitch, int *li, double *lx, int lane, Drain &&drain)
 {
+    constexpr int D = 4;   // chunks in flight per wave: the loads of chunk i + D are issued before chunk i is used
     int cnt = 0;
     const uint64_t lt = lanemask_lt(lane);
-    for (int base = 0; base < pitch; base += CHUNK) {
-        const int e0 = base + 2 * lane;
-        d2 xv = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vals + e0));
-        uint16_t cw = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(codes + e0));
-        const int c0 = cw & 0xff, c1 = cw >> 8;
-        const bool h0 = FILTER == 0 ? !(c0 & CODE_TRAIN) : (c0 & CODE_TEST) != 0;
-        const bool h1 = FILTER == 0 ? !(c1 & CODE_TRAIN) : (c1 & CODE_TEST) != 0;
-        const uint64_t b0 = __ballot(h0), b1 = __ballot(h1);
-        if (b0 | b1) {
-            const int n0 = __popcll(b0);
-            if (h0) { const int pos = cnt + __popcll(b0 & lt); li[pos] = e0; lx[pos] = xv.x; }
-            if (h1) { const int pos = cnt + n0 + __popcll(b1 & lt); li[pos] = e0 + 1; lx[pos] = xv.y; }
-            cnt += n0 + __popcll(b1);
-            if (cnt > LIST_CAP - CHUNK) {
+    d2 xq[D];
+    uint32_t cq[D];   // 32-bit slots: 16-bit ones get packed two per VGPR, which forces a wait on every load
+    const int last = pitch - CHUNK;   // loads past the line are clamped to its last chunk (their data is never used)
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const int e0 = (u * CHUNK < last ? u * CHUNK : last) + 2 * lane;
+        xq[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vals + e0));
+        cq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(codes + e0));
+    }
+    for (int base0 = 0; base0 < pitch; base0 += D * CHUNK) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int base = base0 + u * CHUNK;
+            if (base >= pitch) break;
+            const int e0 = base + 2 * lane;
+            const d2 xv = xq[u];
+            const uint32_t cw = cq[u];
+            const int nb = (base + D * CHUNK < last ? base + D * CHUNK : last) + 2 * lane;
+            const int c0 = cw & 0xff, c1 = cw >> 8;
+            const bool h0 = FILTER == 0 ? !(c0 & CODE_TRAIN) : (c0 & CODE_TEST) != 0;
+            const bool h1 = FILTER == 0 ? !(c1 & CODE_TRAIN) : (c1 & CODE_TEST) != 0;
+            const uint64_t b0 = __ballot(h0), b1 = __ballot(h1);
+            const int n0 = __popcll(b0), n01 = n0 + __popcll(b1);
+            // vmcnt retires in order: a prefetch issued just before a drain would put a full HBM latency in front
+            // of the drain's first gather wait, so in that case it is issued after the drain
+            const bool will_drain = cnt + n01 > LIST_CAP - CHUNK;
+            if (!will_drain) {
+                xq[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vals + nb));
+                cq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(codes + nb));
+            }
+            if (n01) {
+                if (h0) { const int pos = cnt + __popcll(b0 & lt); li[pos] = e0 * TAG_MUL; lx[pos] = xv.x; }
+                if (h1) { const int pos = cnt + n0 + __popcll(b1 & lt); li[pos] = (e0 + 1) * TAG_MUL; lx[pos] = xv.y; }
+                cnt += n01;
+            }
+            if (will_drain) {
                 wave_sync();
                 const int ng = cnt / GROUP;
                 drain(ng);
@@ -112,6 +136,8 @@ __device__ __forceinline__ void stream_line(const double *__restrict__ vals, con
                 wave_sync();
                 if (lane < rem) { li[lane] = ti; lx[lane] = tx; }
                 cnt = rem;
+                xq[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vals + nb));
+                cq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(codes + nb));
             }
         }
     }
@@ -122,34 +148,78 @@ __device__ __forceinline__ void stream_line(const double *__restrict__ vals, con
     wave_sync();
 }
 
-// SYRK drain: four ring entries per step, lane l feeds row (l >> 4) of the 4-deep panel, column (l & 15) of
-// each 16-wide block.  A and B operands of v_mfma_f64_16x16x4_f64 are the same registers (A[i][k] = f~_k[16bi+i],
-// B[k][j] = f~_k[16bj+j]), so a step costs NB gathered loads and NB(NB+1)/2 MFMAs.
+// ---------------------------------------------------------------------------------------------
+// SYRK on gathered rows over a line's precomputed held-out list
+// ---------------------------------------------------------------------------------------------
+// f64 MFMAs hold the SIMD's vector issue port for their whole 64 cycles (measured: a second wave's integer VALU
+// stream makes no progress while one wave issues v_mfma_f64_16x16x4_f64 back to back), so every VALU instruction
+// of this kernel costs MFMA time.  The held-out lists (element index, value) of every line are therefore built
+// ONCE per data set (the masks never change; the reference re-runs find() per gene per iteration,
+// src/optimize.cpp:216-218) and the hot loop is 3 VALU + 2 buffer loads + 2 LDS reads per 3 MFMAs:
+//  * four list entries form a group: lane l feeds entry (l >> 4) of the 4-deep panel, column (l & 15) of each
+//    16-wide block; A and B operands of the MFMA are the same registers (A[i][k] = f~_k[16bi+i], B[k][j] = f~_k[16bj+j]);
+//  * factor rows are fetched with raw buffer loads: 32-bit offset = index * row bytes + column, no 64-bit address
+//    math, and list padding (index LIST_PAD) lands out of range, which the hardware returns as 0;
+//  * the value x rides in the LAST slot (KP - 1) of the padded row: one select on a fixed lane;
+//  * groups go in batches of SYRK_GB with two register sets: batch i+1's gathers are in flight during batch i's MFMAs.
+constexpr int SYRK_GB = 4;
+constexpr int SYRK_BATCH = 4 * SYRK_GB;        // list entries per batch
+constexpr int LIST_ALIGN = 2 * SYRK_BATCH;     // lists are padded to a multiple of two batches (ping-pong drain)
+constexpr int LIST_BLOCK = 64;                 // list entries staged through LDS at a time (one per lane)
+constexpr int LIST_PAD = 0x7FFFFF;             // padding index: index * row bytes is beyond any factor buffer
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
 template <int NB>
-__device__ __forceinline__ void drain_syrk(const int *li, const double *lx, int ngroups, const double *__restrict__ F,
-                                           int K, d4 (&acc)[Geo<NB>::NBLK], int lane)
+__device__ __forceinline__ void syrk_load(const int *li, const double *lx, int batch, __amdgpu_buffer_rsrc_t rsrc,
+                                          double (&a)[SYRK_GB][NB], int lane)
 {
-    constexpr int KP = Geo<NB>::KP;
+    constexpr int RB = Geo<NB>::KP * 8;
     const int sub = lane >> 4, c16 = lane & 15;
-#pragma unroll 2
-    for (int g = 0; g < ngroups; ++g) {
-        const int e = li[4 * g + sub];
-        const double xv = lx[4 * g + sub];
-        double a[NB];
-        const double *row = F + (size_t)(e < 0 ? 0 : e) * KP;
+#pragma unroll
+    for (int u = 0; u < SYRK_GB; ++u) {
+        const int idx = li[SYRK_BATCH * batch + 4 * u + sub];
+        const double xv = lx[SYRK_BATCH * batch + 4 * u + sub];
+        const int off = idx * RB + c16 * 8;   // v_mad_u32_u24
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int col = 16 * b + c16;
-            double v = row[col];
-            v = e < 0 ? 0.0 : v;
-            a[b] = col == K ? xv : v;
+            const v2i w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 128 * b, 0);
+            a[u][b] = __hiloint2double(w.y, w.x);
         }
+        a[u][NB - 1] = c16 == 15 ? xv : a[u][NB - 1];
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void syrk_mfma(const double (&a)[SYRK_GB][NB], d4 (&acc)[Geo<NB>::NBLK])
+{
+#pragma unroll
+    for (int u = 0; u < SYRK_GB; ++u) {
         int blk = 0;
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
             for (int bj = 0; bj <= bi; ++bj, ++blk)
-                acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[blk], 0, 0, 0);
+                acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][bi], a[u][bj], acc[blk], 0, 0, 0);
+    }
+}
+
+// nbatch >= 2, even, batches of SYRK_BATCH staged entries.  All loop control is scalar (readfirstlane) and the
+// MFMAs are unconditional: a branch the compiler cannot prove uniform would make it mirror the accumulators in
+// VGPRs (24 v_accvgpr_read per batch).
+template <int NB>
+__device__ __forceinline__ void drain_syrk(const int *li, const double *lx, int nbatch, __amdgpu_buffer_rsrc_t rsrc,
+                                           d4 (&acc)[Geo<NB>::NBLK], int lane)
+{
+    nbatch = __builtin_amdgcn_readfirstlane(nbatch);
+    double a0[SYRK_GB][NB], a1[SYRK_GB][NB];
+    syrk_load<NB>(li, lx, 0, rsrc, a0, lane);
+    for (int b = 0; b < nbatch; b += 2) {
+        syrk_load<NB>(li, lx, b + 1, rsrc, a1, lane);
+        syrk_mfma<NB>(a0, acc);
+        // clamped look-ahead: re-loading the last batch is harmless and keeps the loads unconditional
+        syrk_load<NB>(li, lx, b + 2 < nbatch ? b + 2 : nbatch - 1, rsrc, a0, lane);
+        syrk_mfma<NB>(a1, acc);
     }
 }
 
@@ -401,39 +471,97 @@ __device__ __forceinline__ bool chol_solve_lds(double *A, int KP, int K, double 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel: complement statistics of every line (row side; also the column side's stand-alone form)
+// Kernel: complement statistics of every line from its held-out list (both sides of the path)
 // ---------------------------------------------------------------------------------------------
-// unit u, segment s: elements [s * seg_len, (s+1) * seg_len) of line u.  Output: Geo<NB>::STAT doubles at
-// stat[(s * units + u) * STAT], block-major [blk][16][16] of the lower blocks of sum f~ f~'.
+// unit u, segment s of nseg: batch pairs [s * per, (s+1) * per) of line u's list.  Output: Geo<NB>::STAT doubles at
+// stat[(s * units + u) * STAT], block-major [blk][16][16] of the lower blocks of sum f~ f~', f~ = [f_e, 0.., x_e].
 template <int NB, int WPB>
 __global__ void __launch_bounds__(WPB * 64)
-k_line_stats(const double *__restrict__ vals, const uint8_t *__restrict__ codes, int64_t pitch, int units, int nseg,
-             int seg_len, const double *__restrict__ F, int K, double *__restrict__ stat)
+k_list_stats(const uint32_t *__restrict__ ptr, const int *__restrict__ lidx, const double *__restrict__ lval, int units,
+             int nseg, const double *__restrict__ F, int64_t f_rows, double *__restrict__ stat)
 {
     constexpr int NBLK = Geo<NB>::NBLK;
-    __shared__ int s_li[WPB][LIST_CAP];
-    __shared__ double s_lx[WPB][LIST_CAP];
+    __shared__ int s_li[WPB][2][LIST_BLOCK];
+    __shared__ double s_lx[WPB][2][LIST_BLOCK];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * WPB + w;
     if (item >= (int64_t)units * nseg) return;
-    const int u = (int)(item % units), s = (int)(item / units);
+    const int u = (int)(item % units), sg = (int)(item / units);
     d4 acc[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-    const int64_t off = (int64_t)u * pitch + (int64_t)s * seg_len;
-    const int64_t left = pitch - (int64_t)s * seg_len;
-    const int this_len = left < seg_len ? (int)left : seg_len;   // both multiples of CHUNK
-    const double *Fs = F + (size_t)s * seg_len * Geo<NB>::KP;
-    int *li = s_li[w];
-    double *lx = s_lx[w];
-    stream_line<0, 4>(vals + off, codes + off, this_len, li, lx, lane,
-                      [&](int ng) { drain_syrk<NB>(li, lx, ng, Fs, K, acc, lane); });
+    const uint32_t e_begin = ptr[u], e_end = ptr[u + 1];
+    const int total = __builtin_amdgcn_readfirstlane((int)((e_end - e_begin) / LIST_ALIGN));   // batch PAIRS in the line
+    const int per = (total + nseg - 1) / nseg;
+    const int b0 = sg * per, b1 = b0 + per < total ? b0 + per : total;
+    if (b0 < b1) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(F), 0, (int)(f_rows * Geo<NB>::KP * 8), 0x00020000);
+        const uint32_t first = e_begin + (uint32_t)b0 * LIST_ALIGN, last = e_begin + (uint32_t)b1 * LIST_ALIGN;
+        const int nblk = __builtin_amdgcn_readfirstlane((int)((last - first + LIST_BLOCK - 1) / LIST_BLOCK));
+        const int nbt = __builtin_amdgcn_readfirstlane((int)((last - first) / SYRK_BATCH));   // even
+        // two list blocks in flight in registers; entries beyond the segment are read as padding
+        auto ld_idx = [&](int blk) { const uint32_t e = first + (uint32_t)blk * LIST_BLOCK + lane; return e < last ? lidx[e] : LIST_PAD; };
+        auto ld_val = [&](int blk) { const uint32_t e = first + (uint32_t)blk * LIST_BLOCK + lane; return e < last ? lval[e] : 0.0; };
+        int i0 = ld_idx(0), i1 = ld_idx(1);
+        double x0 = ld_val(0), x1 = ld_val(1);
+        for (int blk = 0; blk < nblk; ++blk) {
+            int *li = s_li[w][blk & 1];
+            double *lx = s_lx[w][blk & 1];
+            li[lane] = i0;
+            lx[lane] = x0;
+            i0 = i1; x0 = x1;
+            i1 = ld_idx(blk + 2);
+            x1 = ld_val(blk + 2);
+            wave_sync();
+            const int left = nbt - blk * (LIST_BLOCK / SYRK_BATCH);
+            drain_syrk<NB>(li, lx, left < LIST_BLOCK / SYRK_BATCH ? left : LIST_BLOCK / SYRK_BATCH, rsrc, acc, lane);
+        }
+    }
     double *out = stat + (size_t)item * Geo<NB>::STAT;
     const int sub = lane >> 4, c16 = lane & 15;
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[b * 256 + (sub + 4 * r) * 16 + c16] = acc[b][r];
+}
+
+// ---- building the lists (once per data set) -----------------------------------------------------------------
+// number of held-out entries of every line (one wave per line)
+__global__ void __launch_bounds__(256) k_count_heldout(const uint8_t *__restrict__ codes, int64_t pitch, int len,
+                                                       int lines, int *__restrict__ cnt)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= lines) return;
+    int c = 0;
+    for (int i = lane; i < len; i += WAVE) c += !(codes[(size_t)j * pitch + i] & CODE_TRAIN);
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) cnt[j] = c;
+}
+
+// (element index, value) of every held-out entry of a line, ascending, padded to a multiple of LIST_ALIGN
+__global__ void __launch_bounds__(256) k_fill_lists(const double *__restrict__ vals, const uint8_t *__restrict__ codes,
+                                                    int64_t pitch, int len, int lines, const uint32_t *__restrict__ ptr,
+                                                    int *__restrict__ lidx, double *__restrict__ lval)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= lines) return;
+    uint32_t pos = ptr[j];
+    const uint64_t lt = lanemask_lt(lane);
+    for (int base = 0; base < len; base += WAVE) {
+        const int i = base + lane;
+        const bool held = i < len && !(codes[(size_t)j * pitch + i] & CODE_TRAIN);
+        const uint64_t b = __ballot(held);
+        if (held) {
+            const uint32_t o = pos + (uint32_t)__popcll(b & lt);
+            lidx[o] = i;
+            lval[o] = vals[(size_t)j * pitch + i];
+        }
+        pos += (uint32_t)__popcll(b);
+    }
+    for (uint32_t o = pos + lane; o < ptr[j + 1]; o += WAVE) { lidx[o] = LIST_PAD; lval[o] = 0.0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -463,6 +591,8 @@ struct ColArgs {
     int checkpoint;          // also produce per-gene loss statistics
     CdParams cd;
     double *sse_train, *b2, *b1;   // p each (checkpoint only)
+    double *sse_test;        // p; written when test_from_stats
+    int test_from_stats;     // no NA entry in the data: held-out == test, so the test residuals follow from the statistics
     int *sweeps;             // p
     const int *gene_perm;    // launch slot -> gene (genes sorted by their last sweep count, longest first), or null
 };
@@ -495,7 +625,7 @@ __global__ void __launch_bounds__(WPB * 64) k_cd_cols(ColArgs a)
     double q = 0.0, beta = 0.0;
     if (valid) {
         q = a.Qfull[(size_t)j * KP + l];                                                // :222,235 via level sums
-        if (st) q -= st[stat_index(K, l)];                                              // minus the held-out part
+        if (st) q -= st[stat_index(KP - 1, l)];                                         // minus the held-out part
         beta = a.C[(size_t)j * KP + l];
     }
     wave_sync();
@@ -513,10 +643,21 @@ __global__ void __launch_bounds__(WPB * 64) k_cd_cols(ColArgs a)
     const double bqg = group_sum<W>(valid ? beta * (q + g) : 0.0, lane);
     const double sb2 = group_sum<W>(valid ? beta * beta : 0.0, lane);
     const double sb1 = group_sum<W>(valid ? fabs(beta) : 0.0, lane);
+    double te = 0.0;
+    if (a.test_from_stats && st) {
+        // sum_test (x - r'b)^2 = sum_held x^2 - 2 b'qc + b'Gc b, with the complement Gram Gc = R'R - XtX_j:
+        //   b'Gc b = b'(R'R b) - b'(q - g)
+        double rb = 0.0;
+        for (int m = 0; m < K; ++m) rb += (valid ? a.RtR[l * KP + m] : 0.0) * group_bcast<W>(beta, m, lane);
+        const double qc = valid ? st[stat_index(KP - 1, l)] : 0.0;
+        const double part = group_sum<W>(valid ? beta * (rb - (q - g) - 2.0 * qc) : 0.0, lane);
+        te = st[stat_index(KP - 1, KP - 1)] + part;
+    }
     if (gene && l == 0) {
         a.sse_train[j] = a.yy[j] - bqg;
         a.b2[j] = sb2;
         a.b1[j] = sb1;
+        if (a.test_from_stats) a.sse_test[j] = te;
     }
 }
 
@@ -532,6 +673,8 @@ struct RidgeArgs {
     int solve;        // 0: evaluate only
     int checkpoint;
     double *sse_train, *b2, *b1;
+    double *sse_test;
+    int test_from_stats;
     int *fail;
 };
 
@@ -554,7 +697,7 @@ __global__ void __launch_bounds__(WPB * 64) k_ridge_cols(RidgeArgs a)
     load();
     double q = 0.0, beta = 0.0;
     if (valid) {
-        q = a.Qfull[(size_t)j * KP + lane] - (st ? st[stat_index(K, lane)] : 0.0);
+        q = a.Qfull[(size_t)j * KP + lane] - (st ? st[stat_index(KP - 1, lane)] : 0.0);
         beta = a.C[(size_t)j * KP + lane];
     }
     if (a.solve) {
@@ -573,10 +716,18 @@ __global__ void __launch_bounds__(WPB * 64) k_ridge_cols(RidgeArgs a)
     const double bqg = wave_sum(valid ? beta * (q + g) : 0.0);
     const double sb2 = wave_sum(valid ? beta * beta : 0.0);
     const double sb1 = wave_sum(valid ? fabs(beta) : 0.0);
+    double te = 0.0;
+    if (a.test_from_stats && st) {   // as in k_cd_cols
+        double rb = 0.0;
+        for (int m = 0; m < K; ++m) rb += (valid ? a.RtR[lane * KP + m] : 0.0) * readlane_d(beta, m);
+        const double qc = valid ? st[stat_index(KP - 1, lane)] : 0.0;
+        te = st[stat_index(KP - 1, KP - 1)] + wave_sum(valid ? beta * (rb - (q - g) - 2.0 * qc) : 0.0);
+    }
     if (lane == 0) {
         a.sse_train[j] = a.yy[j] - bqg;
         a.b2[j] = sb2;
         a.b1[j] = sb1;
+        if (a.test_from_stats) a.sse_test[j] = te;
     }
 }
 
@@ -597,7 +748,7 @@ k_test_sse(const double *__restrict__ vals, const uint8_t *__restrict__ codes, i
     const double beta = lane < K ? B[(size_t)j * KP + lane] : 0.0;
     const int64_t off = (int64_t)j * pitch;
     double te = 0.0;
-    stream_line<1, 64>(vals + off, codes + off, (int)pitch, li, lx, lane, [&](int ng) {
+    stream_line<1, 64, 1>(vals + off, codes + off, (int)pitch, li, lx, lane, [&](int ng) {
         for (int gi = 0; gi < ng; ++gi) {
             const int e = li[64 * gi + lane];
             const double xv = lx[64 * gi + lane];
@@ -821,7 +972,7 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
             if (lane < KP) s_s[lane] = valid ? s : 0.0;
             wave_sync();
             if (valid) {
-                double y = -s_H[K * KP + lane];            // - bc_r
+                double y = -s_H[(KP - 1) * KP + lane];     // - bc_r (the x slot is the last one of the padded row)
                 for (int b = 0; b < K; ++b) y += s_H[lane * KP + b] * s_s[b];
                 v += y;
             }
@@ -1086,6 +1237,20 @@ __global__ void __launch_bounds__(64) k_line_dense_xty(const double *__restrict_
     }
 }
 
+// the same for sample r against the gene-major X: out[r][k] = sum_j X[j][r] F[j][k]
+__global__ void __launch_bounds__(64) k_row_dense_xty(const double *__restrict__ X, int64_t pitch, int len,
+                                                      const double *__restrict__ F, int K, int KP, double *__restrict__ out)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    for (int k = 0; k < KP; ++k) {
+        double s = 0.0;
+        if (k < K)
+            for (int j = lane; j < len; j += 64) s += X[(size_t)j * pitch + r] * F[(size_t)j * KP + k];
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)r * KP + k] = s;
+    }
+}
+
 // blocks of sum f~ f~' (stat layout) -> dense K x K column-major XtX = full - complement and Xty = qfull - row K
 template <int NB>
 __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict__ stat, int nseg, int units, int K,
@@ -1113,7 +1278,7 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
         const int x = i % K, y = i / K;
         G_out[(size_t)u * K * K + i] = full[x * KP + y] - s_H[x * KP + y];
     }
-    if (lane < K) q_out[(size_t)u * K + lane] = qfull[(size_t)u * KP + lane] - s_H[K * KP + lane];
+    if (lane < K) q_out[(size_t)u * K + lane] = qfull[(size_t)u * KP + lane] - s_H[(KP - 1) * KP + lane];
 }
 
 }  // namespace insider
