@@ -106,7 +106,7 @@ struct insider_hip_handle {
     insider_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
     // options
-    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0, dbg_skip_drain = 0;
+    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0, dbg_skip_drain = 0, cd_variant = 0;
     // profile of the last optimize()
     std::vector<hipEvent_t> ev_col, ev_row, ev_cd, ev_test;
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -357,7 +357,12 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.test_from_stats = masked && h->no_na;
         a.sweeps = h->sweeps;
         a.gene_perm = (solve && h->have_perm) ? h->gene_perm : nullptr;
-        if (h->K <= 16) hipLaunchKernelGGL((k_cd_cols<16, 4>), dim3(cdiv(h->p, 16)), dim3(256), 0, h->stream, a);
+        const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
+        if (h->cd_variant == 0 && h->K <= 16)
+            hipLaunchKernelGGL((k_cd_cols_r16<1>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
+        else if (h->cd_variant == 0 && h->K <= 32)
+            hipLaunchKernelGGL((k_cd_cols_r16<2>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
+        else if (h->K <= 16) hipLaunchKernelGGL((k_cd_cols<16, 4>), dim3(cdiv(h->p, 16)), dim3(256), 0, h->stream, a);
         else if (h->K <= 32) hipLaunchKernelGGL((k_cd_cols<32, 2>), dim3(cdiv(h->p, 4)), dim3(128), 0, h->stream, a);
         else hipLaunchKernelGGL((k_cd_cols<64, 1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
         KCHECK();
@@ -763,7 +768,8 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "order_mode") h->order_mode = (int)value;
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
-    else if (s == "dbg_skip_drain") h->dbg_skip_drain = (int)value;   // diagnostics: time the streaming/compaction alone
+    else if (s == "dbg_skip_drain") h->dbg_skip_drain = (int)value;
+    else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = row16 (4 genes per wave, K <= 32), 1 = group kernel
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
 }
@@ -971,10 +977,11 @@ int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *ws
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
     HIPCHECK(hipEventRecord(e0, 0));
-    if (K <= 16) hipLaunchKernelGGL((k_cd_batch<16, 4>), dim3(cdiv(nprob, 16)), dim3(256), 0, 0, (const double *)dG,
+    const size_t r16_bytes = (size_t)r16_lds_doubles(K) * sizeof(double);
+    if (K <= 16) hipLaunchKernelGGL((k_cd_batch_r16<1>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, (const double *)dG,
                                     (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
-    else if (K <= 32) hipLaunchKernelGGL((k_cd_batch<32, 2>), dim3(cdiv(nprob, 4)), dim3(128), 0, 0, (const double *)dG,
-                                         (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+    else if (K <= 32) hipLaunchKernelGGL((k_cd_batch_r16<2>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0,
+                                         (const double *)dG, (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
     else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, (const double *)dG,
                             (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
     KCHECK();

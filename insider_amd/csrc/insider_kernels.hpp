@@ -1282,3 +1282,5 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
 }
 
 }  // namespace insider
+
+#include "insider_cd_row16.hpp"
