@@ -45,13 +45,13 @@ struct R16State {
 
 // One coordinate update at the static position T (src/coordinate_descent.cpp:91-110 in covariance form).
 template <int SLOTS, int T>
-__device__ __forceinline__ void r16_step(R16State<SLOTS> &S, const char *L, uint32_t stepmask, const uint32_t (&ordw)[8],
-                                         int pitchB, double la, int lane16)
+__device__ __forceinline__ void r16_step(R16State<SLOTS> &S, const char *L, const uint32_t (&ordw)[8 * SLOTS], double la,
+                                         int lane16)
 {
     constexpr int s = T >> 4, it = T & 15;
     if constexpr (s < SLOTS) {
         // unconditional: positions beyond K and screened-out coordinates carry inv = beta = 0, i.e. a zero increment
-        const int rowoff = (int)((ordw[T >> 2] >> (8 * (T & 3))) & 0xffu) * pitchB;       // scalar
+        const int rowoff = (int)((ordw[T >> 1] >> (16 * (T & 1))) & 0xffffu);   // scalar: coordinate * pitch bytes
         double g[SLOTS];
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) g[u] = *reinterpret_cast<const double *>(L + (S.col[u] + rowoff));
@@ -168,13 +168,13 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
 
     while (__any(run)) {
         // ---- this sweep's order: scalar copy for the row offsets, per-lane ids (prefetched) for the columns -----
-        const uint32_t *orow = reinterpret_cast<const uint32_t *>(P.order + (size_t)sweep * 64);
-        uint32_t ordw[8];
+        const uint32_t *orow = reinterpret_cast<const uint32_t *>(P.order + (size_t)sweep * ORDER_ROW + 64);
+        uint32_t ordw[8 * SLOTS];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) ordw[w] = __builtin_amdgcn_readfirstlane((int)orow[w]);
+        for (int w = 0; w < 8 * SLOTS; ++w) ordw[w] = __builtin_amdgcn_readfirstlane((int)orow[w]);
         int nn[SLOTS];
         {
-            const size_t nx = (size_t)(sweep + 1 < P.max_sweeps ? sweep + 1 : sweep) * 64;
+            const size_t nx = (size_t)(sweep + 1 < P.max_sweeps ? sweep + 1 : sweep) * ORDER_ROW;
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) nn[u] = 16 * u + i < K ? (int)P.order[nx + 16 * u + i] : 0;
         }
@@ -198,14 +198,13 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
             S.col[u] = gbase + cid[u] * 8;
         }
         wave_sync();
-        const uint32_t stepmask = 0;
         double beta0[SLOTS], g0[SLOTS];
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) { beta0[u] = S.beta[u]; g0[u] = S.h[u] - S.beta[u] * gl[u]; }
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
         // straight-line blocks of four steps (one scalar branch per block) so that the scheduler can hoist the
         // next steps' address arithmetic and LDS reads into the stalls of the dependent chain
-#define R16_S(T) r16_step<SLOTS, T>(S, L, stepmask, ordw, pitchB, la, i);
+#define R16_S(T) r16_step<SLOTS, T>(S, L, ordw, la, i);
 #define R16_B(B) if (4 * (B) < K) { R16_S(4 * (B)) R16_S(4 * (B) + 1) R16_S(4 * (B) + 2) R16_S(4 * (B) + 3) }
         R16_B(0) R16_B(1) R16_B(2) R16_B(3) R16_B(4) R16_B(5) R16_B(6) R16_B(7)
 #undef R16_B

@@ -280,12 +280,12 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     if (h->order_rows < max_sweeps) {
         if (h->order) (void)hipFree(h->order);
         h->order = nullptr;
-        int rc = dmalloc(&h->order, (size_t)max_sweeps * 64);
+        int rc = dmalloc(&h->order, (size_t)max_sweeps * ORDER_ROW);
         if (rc) return rc;
         h->order_rows = max_sweeps;
     }
-    hipLaunchKernelGGL(k_order_table, dim3(cdiv(max_sweeps, 64)), dim3(64), 0, h->stream, seed, iter, K, max_sweeps,
-                       order_mode, h->order);
+    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)max_sweeps * 64, 256)), dim3(256), 0, h->stream, seed, iter, K,
+                       max_sweeps, order_mode, K * 8, h->order);
     KCHECK();
     return INSIDER_OK;
 }
@@ -964,8 +964,9 @@ int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *ws
     HIPCHECK(hipMemcpy(dw, wstart, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
     const int ms = max_sweeps < 1 ? 1 : max_sweeps;
     uint8_t *dord = nullptr;
-    if ((rc = dmalloc(&dord, (size_t)ms * 64))) return rc;
-    hipLaunchKernelGGL(k_order_table, dim3(cdiv(ms, 64)), dim3(64), 0, 0, seed, iter, K, ms, order_mode, dord);
+    if ((rc = dmalloc(&dord, (size_t)ms * ORDER_ROW))) return rc;
+    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)ms * 64, 256)), dim3(256), 0, 0, seed, iter, K, ms, order_mode, K * 8,
+                       dord);
     KCHECK();
     CdParams cd;
     cd.lambda = lambda;

@@ -31,6 +31,8 @@ constexpr int WAVE = 64;
 constexpr int LIST_CAP = 512;   // held-out ring entries per wave (>= 2 * 128)
 constexpr int CHUNK = 128;      // elements per streaming step (2 per lane); line pitches are multiples of it
 
+constexpr int ORDER_ROW = 128;   // bytes per sweep in the coordinate-order table (see k_order_table)
+
 constexpr int CODE_TRAIN = 1;   // bit 0 of a mask code: entry is in the train set
 constexpr int CODE_TEST = 2;    // bit 1: entry is in the test set (neither bit: NA)
 
@@ -263,7 +265,7 @@ __device__ __forceinline__ void acc_to_lds(const d4 (&acc)[Geo<NB>::NBLK], doubl
 struct CdParams {
     double lambda, alpha, tol;
     int max_sweeps;
-    const uint8_t *order;   // [max_sweeps][64]: row s, entry t = t-th coordinate of sweep s (all K coordinates)
+    const uint8_t *order;   // [max_sweeps][ORDER_ROW], see k_order_table
 };
 
 template <int W>
@@ -349,7 +351,7 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
     double bfinal = beta, gfinal = 0.0;
     uint32_t ordv = lane < K ? P.order[lane] : 0u;
     while (__any(run)) {
-        const uint32_t ordn = (lane < K && sweep + 1 < P.max_sweeps) ? P.order[(size_t)(sweep + 1) * 64 + lane] : 0u;
+        const uint32_t ordn = (lane < K && sweep + 1 < P.max_sweeps) ? P.order[(size_t)(sweep + 1) * ORDER_ROW + lane] : 0u;
         // this sweep's coordinate list: the table row without the coordinates screened out in every group (:83)
         uint64_t am = __ballot(active);
         if constexpr (W == 32) am = (am | (am >> 32)) & 0xffffffffull;
@@ -411,25 +413,30 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
     return my_sweeps;
 }
 
-// order[s][t] for s < nsweeps: all K coordinates in ascending key order (order_mode 0) or 0..K-1 (cyclic)
-__global__ void k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
-                              uint8_t *__restrict__ order)
+// Order table, one row of ORDER_ROW bytes per sweep s < nsweeps: bytes [0, 64): the K coordinates in ascending key
+// order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
+// the row16 kernel, K <= 32).  One thread per (sweep, coordinate): rank by counting.
+__global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
+                                                     int pitch_bytes, uint8_t *__restrict__ order)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t >> 6, l = t & 63;
     if (s >= nsweeps) return;
-    uint32_t keys[64];
-    uint8_t ord[64];
-    const uint32_t base = insider_perm_base(seed, iter, (uint32_t)s);
-    for (int i = 0; i < K; ++i) { keys[i] = order_mode == 0 ? insider_perm_key(base, (uint32_t)i) : (uint32_t)i; ord[i] = (uint8_t)i; }
-    for (int i = 1; i < K; ++i) {
-        const uint32_t kk = keys[i];
-        const uint8_t v = ord[i];
-        int j = i - 1;
-        while (j >= 0 && keys[j] > kk) { keys[j + 1] = keys[j]; ord[j + 1] = ord[j]; --j; }
-        keys[j + 1] = kk;
-        ord[j + 1] = v;
+    uint8_t *row = order + (size_t)s * ORDER_ROW;
+    if (l >= K) {
+        row[l] = 0;
+        if (l < 32) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
+        return;
     }
-    for (int i = 0; i < 64; ++i) order[(size_t)s * 64 + i] = i < K ? ord[i] : 0;
+    int rank = l;
+    if (order_mode == 0) {
+        const uint32_t base = insider_perm_base(seed, iter, (uint32_t)s);
+        const uint32_t key = insider_perm_key(base, (uint32_t)l);
+        rank = 0;
+        for (int m = 0; m < K; ++m) rank += insider_perm_key(base, (uint32_t)m) < key;
+    }
+    row[rank] = (uint8_t)l;
+    if (rank < 32) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
 }
 
 // ---------------------------------------------------------------------------------------------
