@@ -42,6 +42,18 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter):
     """The CPU oracle (reference formulation: residual-form CD, cube slices, materialised residual) on a bounded
     sample: the first `genes` genes of the same workload, all samples, 1 outer iteration, phases timed separately.
@@ -173,7 +185,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(name, lam, alpha, os.cpu_count() or 1,
+                out["cpu_baseline"] = cpu_baseline(name, lam, alpha, host_cores(),
                                                    out["cd_kernel"]["sweeps_per_gene_per_iter"])
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "outer-iterations/s", "cores": 0, "kind": "port",
