@@ -153,6 +153,8 @@ CASES = {
     "ridge": dict(alpha=0.0),
     "ridge_unmasked": dict(alpha=0.0, tuning=0),
     "k17": dict(K=17, n=90, p=120),
+    "k30": dict(K=30, n=150, p=90),          # row16 kernel, two slots, 2 padded positions
+    "k40": dict(K=40, n=150, p=60),          # K > 32: one gene per wavefront (group kernel), 3x3 MFMA blocks
     "three_cov": dict(level_counts=(4, 3, 5), n=120, p=100),
 }
 
@@ -193,6 +195,34 @@ def test_optimize_31_iterations(oracle, case):
     assert got["loss"] == pytest.approx(ref["loss"], rel=1e-9)
     if w.tuning == 0:
         assert np.isnan(got["test_rmse"])
+
+
+@pytest.mark.parametrize("opts", [dict(cd_variant=1), dict(order_mode=1), dict(max_sweeps=7),
+                                  dict(cd_variant=1, max_sweeps=5, order_mode=1)])
+def test_optimize_options(oracle, opts):
+    # the alternative CD kernel (one group of lanes per gene), cyclic sweep order, and the sweep cap
+    w = workloads.small(K=9, n=70, p=90, with_na=True)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    for k, v in opts.items():
+        ds.set_option(k, v)
+    got = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=12, seed=31)
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, max_iter=12,
+                          seed=31, order_mode=opts.get("order_mode", 0), max_sweeps=opts.get("max_sweeps", 10000))
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-7
+
+
+def test_sweep_counts_match_oracle(oracle):
+    w = workloads.small(K=12, n=80, p=64)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.set_option("profile", 1)
+    ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=4, seed=9)
+    total = ds.profile()["sweeps"]
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, max_iter=4,
+                          seed=9)
+    assert abs(total - ref["total_sweeps"]) <= max(3, 0.002 * ref["total_sweeps"])
 
 
 def test_inplace_update_and_oneshot_operator(oracle):
