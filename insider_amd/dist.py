@@ -95,11 +95,14 @@ class DeviceAllreduce:
         self.calls.append(count)
 
 
-def attach(ds, gene_offset, rank, world, device=None, group=None):
-    """Mark an InsiderData handle as one gene slab of a `world`-rank job and install the RCCL all-reduce."""
-    if world <= 1:
+def attach(ds, gene_offset, rank, world, device=None, group=None, force=False):
+    """Mark an InsiderData handle as one gene slab of a `world`-rank job and install the RCCL all-reduce.
+    ``force``: install (and call) the all-reduce even for world == 1 (plumbing rehearsal on a single GPU)."""
+    if world <= 1 and not force:
         ds.set_shard(gene_offset, 0, 1, None)
         return None
     ar = DeviceAllreduce(device if device is not None else 0, group)
     ds.set_shard(gene_offset, rank, world, ar)
+    if force:
+        ds.set_option("force_allreduce", 1)
     return ar

@@ -318,3 +318,32 @@ def test_c2_all_ones_mask_equals_unmasked(c2):
     ds.close()
     assert relerr(r1["column_factor"], r0["column_factor"]) < 1e-9
     np.testing.assert_allclose(r1["traj"][:, 3:8], r0["traj"][:, 3:8], rtol=1e-10)
+
+
+def test_allreduce_callback_plumbing_single_gpu(oracle):
+    """The exchange path of the gene-sharded driver on one GPU: torch.distributed (nccl = RCCL) with world_size 1, the
+    library calling back with DEVICE pointers (per covariate per outer iteration + per checkpoint).  A sum over one
+    rank is the identity, so the results must equal the unsharded run bit for bit."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from insider_amd import dist as idist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        w = workloads.small(K=6, n=70, p=96)
+        ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+        plain = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=10, seed=4)
+        ar = idist.attach(ds, 0, 0, 1, device=0, force=True)
+        forced = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=10, seed=4)
+        ds.close()
+        assert np.array_equal(plain["column_factor"], forced["column_factor"])
+        assert np.array_equal(plain["traj"], forced["traj"], equal_nan=True)
+        KP = 16
+        per_iter = [int(L) * (KP * KP + KP) for L in w.n_levels]
+        # 11 outer iterations x one all-reduce per covariate, + 6 doubles per loss evaluation (initial + iter 0, 10)
+        assert ar.calls == [6] + (per_iter * 1 + [6]) + per_iter * 9 + per_iter + [6]
+    finally:
+        dist.destroy_process_group()
