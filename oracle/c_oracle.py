@@ -141,7 +141,7 @@ def optimize_col(X, M, R, Cmat, lam, alpha, tuning=1, tol=1e-5, seed=0, it=0, or
 
 def optimize(X, levels, n_levels, A_list, Cmat, M_train, M_test, lam1, lam2, alpha, tuning=1, global_tol=1e-10,
              sub_tol=1e-5, max_iter=10000, seed=0, order_mode=0, max_sweeps=10000, row_threads=10, col_threads=30,
-             traj_cap=4096):
+             traj_cap=4096, ctns=None):
     """The reference's optimize() (src/optimize.cpp:255-422), categorical covariates only.
 
     Returns dict(row_matrices, column_factor, train_rmse, test_rmse, loss, traj, iters, total_sweeps);
@@ -157,7 +157,14 @@ def optimize(X, levels, n_levels, A_list, Cmat, M_train, M_test, lam1, lam2, alp
     K = Cout.shape[0]
     Mtr = np.asfortranarray(M_train, dtype=np.uint8)
     Mte = np.asfortranarray(M_test, dtype=np.uint8)
-    Aptrs = (C.POINTER(C.c_double) * c)(*[_p(a) for a in A])
+    Aptrs = (C.POINTER(C.c_double) * len(A))(*[_p(a) for a in A])
+    if ctns is not None:
+        ctns = _f64(np.asarray(ctns, dtype=np.float64).reshape(n, -1))
+        m = ctns.shape[1]
+        assert len(A) == c + 1 and A[c].shape == (m, K)
+    else:
+        m = 0
+        assert len(A) == c
     traj = np.full((traj_cap, TRAJ_STRIDE), np.nan)
     tr = C.c_double()
     te = C.c_double()
@@ -167,7 +174,8 @@ def optimize(X, levels, n_levels, A_list, Cmat, M_train, M_test, lam1, lam2, alp
     sw = C.c_int64()
     phases = np.zeros(3)
     rc = lib().oracle_optimize(_p(X), C.c_int(n), C.c_int(p), _p(levels, C.c_int32), C.c_int(c),
-                               _p(n_levels, C.c_int32), Aptrs, _p(Cout), _p(Mtr, C.c_uint8), _p(Mte, C.c_uint8),
+                               _p(n_levels, C.c_int32), _p(ctns) if m else None, C.c_int(m), Aptrs, _p(Cout),
+                               _p(Mtr, C.c_uint8), _p(Mte, C.c_uint8),
                                C.c_int(K), C.c_double(lam1), C.c_double(lam2), C.c_double(alpha), C.c_int(tuning),
                                C.c_double(global_tol), C.c_double(sub_tol), C.c_uint32(max_iter), C.c_uint64(seed),
                                C.c_int(order_mode), C.c_int(max_sweeps), C.c_int(row_threads), C.c_int(col_threads),
@@ -178,3 +186,20 @@ def optimize(X, levels, n_levels, A_list, Cmat, M_train, M_test, lam1, lam2, alp
     return dict(row_matrices=A, column_factor=Cout, train_rmse=tr.value, test_rmse=te.value, loss=lo.value,
                 traj=traj[:rows.value].copy(), iters=iters.value, total_sweeps=sw.value,
                 phase_seconds=dict(row=phases[0], col=phases[1], residual_eval=phases[2]))
+
+
+def optimize_continuous(data, M, u, Cmat, z, gram, lam, tuning=1, n_threads=8):
+    """optimize_continuous_v2 (reference src/optimize.cpp:76-137); returns the updated K-vector."""
+    data = _f64(data)
+    M = np.asfortranarray(M, dtype=np.uint8)
+    Cmat = _f64(Cmat)
+    gram = _f64(gram)
+    z = _f64(z)
+    u = _f64(u).copy()
+    n, p = data.shape
+    K = Cmat.shape[0]
+    rc = lib().oracle_optimize_continuous(_p(data), _p(M, C.c_uint8), _p(u), _p(Cmat), _p(z), _p(gram), C.c_double(lam),
+                                          C.c_int(tuning), C.c_int(n), C.c_int(p), C.c_int(K), C.c_int(n_threads))
+    if rc:
+        raise RuntimeError(f"oracle_optimize_continuous failed rc={rc}")
+    return u

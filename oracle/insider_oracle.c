@@ -350,6 +350,81 @@ int oracle_optimize_row(const double *residual, const uint8_t *M, double *A /*L 
 }
 
 /* ------------------------------------------------------------------------- */
+/* optimize_continuous_v2 — src/optimize.cpp:76-137                          */
+/* data: the residual with this column's contribution added back (n x p);    */
+/* u: the K-vector being updated (row j of the continuous factor).           */
+/* ------------------------------------------------------------------------- */
+int oracle_optimize_continuous(const double *data, const uint8_t *M, double *u, const double *C, const double *z,
+                               const double *gram, double lambda, int tuning, int n, int p, int K, int n_threads)
+{
+    if (tuning != 0 && tuning != 1) return ORACLE_ERR_ARG;
+    if (tuning == 0) {                                                        /* :127-131 */
+        double *Xty = (double *)calloc((size_t)K, sizeof(double));
+        double *XtX = (double *)malloc(sizeof(double) * (size_t)K * K);
+        double zz = 0.0;
+        for (int r = 0; r < n; r++) zz += z[r] * z[r];
+        for (int j = 0; j < p; j++) {
+            double t = 0.0;
+            for (int r = 0; r < n; r++) t += data[r + (size_t)j * n] * z[r];      /* data' z */
+            for (int a = 0; a < K; a++) Xty[a] += C[a + (size_t)j * K] * t;       /* C (data' z) */
+        }
+        for (int a = 0; a < K * K; a++) XtX[a] = zz * gram[a];
+        for (int a = 0; a < K; a++) XtX[a + (size_t)a * K] += lambda;
+        int rc = solve_likely_sympd(XtX, Xty, K, 1);
+        if (rc == ORACLE_OK) for (int a = 0; a < K; a++) u[a] = Xty[a];
+        free(Xty); free(XtX);
+        return rc;
+    }
+    size_t np = (size_t)n * p;
+    double *resid = (double *)malloc(sizeof(double) * np);
+    double *pre = (double *)malloc(sizeof(double) * (size_t)K);
+    double *normf = (double *)calloc((size_t)K, sizeof(double));
+    if (!resid || !pre || !normf) { free(resid); free(pre); free(normf); return ORACLE_ERR_ALLOC; }
+    /* :84 resid = data - z u C */
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int j = 0; j < p; j++) {
+        double t = 0.0;
+        for (int a = 0; a < K; a++) t += u[a] * C[a + (size_t)j * K];
+        for (int r = 0; r < n; r++) resid[r + (size_t)j * n] = data[r + (size_t)j * n] - z[r] * t;
+    }
+    for (int j = 0; j < p; j++)                                                /* :90 norm_factor = rowsums(C^2) */
+        for (int a = 0; a < K; a++) normf[a] += C[a + (size_t)j * K] * C[a + (size_t)j * K];
+    for (;;) {                                                                  /* :102 */
+        for (int a = 0; a < K; a++) pre[a] = u[a];
+        for (int i = 0; i < K; i++) {                                           /* :104 */
+            double XtX = 0.0, Xty = 0.0;
+#pragma omp parallel for num_threads(n_threads) schedule(static) reduction(+ : Xty)
+            for (int j = 0; j < p; j++) {
+                const double ci = C[i + (size_t)j * K], f = u[i] * ci;
+                double t = 0.0;
+                for (int r = 0; r < n; r++) {
+                    resid[r + (size_t)j * n] += f * z[r];                       /* :107 */
+                    if (M[r + (size_t)j * n]) t += z[r] * resid[r + (size_t)j * n];
+                }
+                Xty += t * ci;                                                  /* :111 */
+            }
+            for (int r = 0; r < n; r++) {                                       /* :112-114 */
+                double zs = 0.0;
+                for (int j = 0; j < p; j++)
+                    if (M[r + (size_t)j * n] == 0) zs += C[i + (size_t)j * K] * C[i + (size_t)j * K];
+                XtX += z[r] * z[r] * (normf[i] - zs);
+            }
+            u[i] = Xty / (XtX + lambda);                                        /* :117 */
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+            for (int j = 0; j < p; j++) {                                       /* :118 */
+                const double f = u[i] * C[i + (size_t)j * K];
+                for (int r = 0; r < n; r++) resid[r + (size_t)j * n] -= f * z[r];
+            }
+        }
+        double d = 0.0;
+        for (int a = 0; a < K; a++) d += fabs(pre[a] - u[a]);
+        if (d < 1e-1) break;                                                    /* :122 */
+    }
+    free(resid); free(pre); free(normf);
+    return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------- */
 /* optimize_col — src/optimize.cpp:200-253                                   */
 /* ------------------------------------------------------------------------- */
 int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x K*/, double *C /*K x p*/,
@@ -537,13 +612,13 @@ static void evaluate(const double *resid, const uint8_t *Mtr, const uint8_t *Mte
 }
 
 /* compute_loss(field) — src/utils.cpp:79-102; comps = {SSE/2, row_reg/2, col_reg/2, l1_reg} */
-static double global_loss(double *const *A, const int32_t *n_levels, int c, const double *C, int p, int K,
+static double global_loss(double *const *A, const int32_t *n_levels, int c, int m, const double *C, int p, int K,
                           double lambda1, double lambda2, double alpha, double sum_residual, double *comps)
 {
     double row_reg = 0.0;
-    for (int i = 0; i < c; i++) {
+    for (int i = 0; i < c + (m > 0 ? 1 : 0); i++) {
         double s = 0.0;
-        size_t cnt = (size_t)n_levels[i] * K;
+        size_t cnt = (size_t)(i < c ? n_levels[i] : m) * K;
         for (size_t e = 0; e < cnt; e++) s += A[i][e] * A[i][e];
         double nf = sqrt(s);
         row_reg += lambda1 * nf * nf;
@@ -558,15 +633,42 @@ static double global_loss(double *const *A, const int32_t *n_levels, int c, cons
     return sum_residual / 2 + row_reg / 2 + col_reg / 2 + l1_reg;
 }
 
+static void build_row_factor(double *R, double *const *A, const int32_t *levels, const int32_t *n_levels, int c,
+                             const double *ctns, int m, int n, int K)
+{
+    for (size_t e = 0; e < (size_t)n * K; e++) R[e] = 0.0;
+    for (int i = 0; i < c; i++)
+        for (int k = 0; k < K; k++)
+            for (int r = 0; r < n; r++)
+                R[r + (size_t)k * n] += A[i][(levels[r + (size_t)i * n] - 1) + (size_t)k * n_levels[i]];
+    for (int j = 0; j < m; j++)                                   /* :289,372  ctns_confounder * cfd_matrices(last) */
+        for (int k = 0; k < K; k++)
+            for (int r = 0; r < n; r++) R[r + (size_t)k * n] += ctns[r + (size_t)j * n] * A[c][j + (size_t)k * m];
+}
+
+/* residual += sgn * z (u C)   (src/optimize.cpp:344,348) */
+static void residual_add_cont(double *resid, const double *z, const double *u, const double *C, double sgn, int n, int p,
+                              int K, int n_threads)
+{
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int j = 0; j < p; j++) {
+        double t = 0.0;
+        for (int a = 0; a < K; a++) t += u[a] * C[a + (size_t)j * K];
+        t *= sgn;
+        for (int r = 0; r < n; r++) resid[r + (size_t)j * n] += z[r] * t;
+    }
+}
+
 /* ------------------------------------------------------------------------- */
-/* optimize — src/optimize.cpp:255-422 (categorical covariates only)          */
+/* optimize — src/optimize.cpp:255-422                                        */
 /* ------------------------------------------------------------------------- */
 #define ORACLE_TRAJ_STRIDE 10
 /* traj rows: {iter, train_rmse, test_rmse, SSE/2, row_reg/2, col_reg/2, l1_reg, loss, delta_loss, decay};
  * row 0 is the evaluation of the initial values (:320-323, iter = -1 marker),
  * then one row per checkpoint (:381-408).                                    */
 int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c*/, int c, const int32_t *n_levels,
-                    double *const *A /*c ptrs, L_i x K, in/out*/, double *C /*K x p in/out*/, const uint8_t *Mtr,
+                    const double *ctns /*n x m continuous covariates or NULL*/, int m,
+                    double *const *A /*c (+1 if m > 0) ptrs: L_i x K, then m x K; in/out*/, double *C /*K x p in/out*/, const uint8_t *Mtr,
                     const uint8_t *Mte, int K, double lambda1, double lambda2, double alpha, int tuning,
                     double global_tol, double sub_tol, uint32_t max_iter, uint64_t seed, int order_mode,
                     int max_sweeps, int row_threads, int col_threads, double *out_train_rmse,
@@ -589,18 +691,14 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
     int rc = ORACLE_OK, trows = 0;
     int64_t sweeps_total = 0;
 
-    /* :281-291 row_factor = sum_i A_i[level_i] */
-    for (size_t e = 0; e < (size_t)n * K; e++) R[e] = 0.0;
-    for (int i = 0; i < c; i++)
-        for (int k = 0; k < K; k++)
-            for (int r = 0; r < n; r++)
-                R[r + (size_t)k * n] += A[i][(levels[r + (size_t)i * n] - 1) + (size_t)k * n_levels[i]];
+    /* :281-291 row_factor = sum_i A_i[level_i] (+ ctns * A_last) */
+    build_row_factor(R, A, levels, n_levels, c, ctns, m, n, K);
 
     double sum_residual, train_rmse, test_rmse, loss, pre_loss, delta_loss, decay = 1.0, comps[4];
     tp = now_s();
     residual_from_scratch(X, R, C, resid, n, p, K, col_threads);                           /* :320-321 */
     evaluate(resid, Mtr, Mte, tuning, n, p, &sum_residual, &train_rmse, &test_rmse, col_threads); /* :322 */
-    loss = global_loss(A, n_levels, c, C, p, K, lambda1, lambda2, alpha, sum_residual, comps);    /* :323 */
+    loss = global_loss(A, n_levels, c, m, C, p, K, lambda1, lambda2, alpha, sum_residual, comps); /* :323 */
     if (traj && trows < traj_cap) {
         double *t = traj + (size_t)trows * ORACLE_TRAJ_STRIDE;
         t[0] = -1; t[1] = train_rmse; t[2] = test_rmse; t[3] = comps[0]; t[4] = comps[1]; t[5] = comps[2];
@@ -619,23 +717,32 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
                 for (int j = 0; j < p; j++) s += C[a + (size_t)j * K] * C[b + (size_t)j * K];
                 gram[a + (size_t)b * K] = s;
             }
+        const int cfd_num = c + (m > 0 ? 1 : 0);                                           /* :276-278 */
         for (int i = 0; i < c && rc == ORACLE_OK; i++) {                                   /* :335 */
             const int32_t *lev = levels + (size_t)i * n;
             residual_add_cov(resid, A[i], n_levels[i], lev, C, +1.0, n, p, K, col_threads); /* :338 */
             rc = oracle_optimize_row(resid, Mtr, A[i], C, lev, gram, lambda1, tuning, n, p, K, n_levels[i],
                                      row_threads);                                          /* :339 */
-            if (i != c - 1)                                                                 /* :353-355 */
+            if (i != cfd_num - 1)                                                           /* :353-355 */
                 residual_add_cov(resid, A[i], n_levels[i], lev, C, -1.0, n, p, K, col_threads);
+        }
+        if (m > 0 && rc == ORACLE_OK) {                                                     /* :340-351 */
+            double *u = (double *)malloc(sizeof(double) * (size_t)K);
+            for (int j = 0; j < m && rc == ORACLE_OK; j++) {
+                const double *z = ctns + (size_t)j * n;
+                for (int a = 0; a < K; a++) u[a] = A[c][j + (size_t)a * m];
+                residual_add_cont(resid, z, u, C, +1.0, n, p, K, col_threads);              /* :344 */
+                rc = oracle_optimize_continuous(resid, Mtr, u, C, z, gram, lambda1, tuning, n, p, K, col_threads); /* :345 */
+                for (int a = 0; a < K; a++) A[c][j + (size_t)a * m] = u[a];                 /* :346 */
+                if (j != m - 1) residual_add_cont(resid, z, u, C, -1.0, n, p, K, col_threads);  /* :347-349 */
+            }
+            free(u);
         }
         if (rc != ORACLE_OK) break;
         ph[0] += now_s() - tp;
         tp = now_s();
-        /* :365-369 */
-        for (size_t e = 0; e < (size_t)n * K; e++) R[e] = 0.0;
-        for (int i = 0; i < c; i++)
-            for (int k = 0; k < K; k++)
-                for (int r = 0; r < n; r++)
-                    R[r + (size_t)k * n] += A[i][(levels[r + (size_t)i * n] - 1) + (size_t)k * n_levels[i]];
+        /* :365-373 */
+        build_row_factor(R, A, levels, n_levels, c, ctns, m, n, K);
         /* :376 */
         int64_t sw = 0;
         rc = oracle_optimize_col(X, Mtr, R, C, lambda2, alpha, tuning, sub_tol * decay, n, p, K, seed, iter,
@@ -649,7 +756,7 @@ int oracle_optimize(const double *X, int n, int p, const int32_t *levels /*n x c
         if (iter % 10 == 0) {                                                               /* :381-408 */
             pre_loss = loss;
             evaluate(resid, Mtr, Mte, tuning, n, p, &sum_residual, &train_rmse, &test_rmse, col_threads);
-            loss = global_loss(A, n_levels, c, C, p, K, lambda1, lambda2, alpha, sum_residual, comps);
+            loss = global_loss(A, n_levels, c, m, C, p, K, lambda1, lambda2, alpha, sum_residual, comps);
             delta_loss = pre_loss - loss;
             if (delta_loss / 1000 <= 1e-6) decay = 1e-6;
             else if (delta_loss / 1000 <= 1e-5) decay = 1e-5;

@@ -122,6 +122,37 @@ def optimize_row(residual, indicator, updating_factor, c_factor, updating_confd,
     return out
 
 
+# -- src/optimize.cpp:76-137 ----------------------------------------------------
+def optimize_continuous_v2(data, indicator, updating_factor, c_factor, updating_confd, gram, lam, tuning):
+    u = np.array(updating_factor, float).copy()
+    z = np.asarray(updating_confd, float)
+    K = c_factor.shape[0]
+    if tuning == 1:
+        resid = data - np.outer(z, u @ c_factor)                                 # :84
+        squared_factor = c_factor ** 2                                           # :88
+        squared_confd = z ** 2
+        norm_factor = squared_factor.sum(axis=1)                                 # :90
+        zero_idx = [np.flatnonzero(indicator[k, :] == 0) for k in range(indicator.shape[0])]   # :92-95
+        while True:
+            pre = u.copy()                                                       # :103
+            for i in range(K):
+                resid = resid + u[i] * np.outer(z, c_factor[i, :])               # :107
+                Xty = float(z @ (indicator * resid) @ c_factor[i, :])            # :111
+                XtX = sum(squared_confd[k] * (norm_factor[i] - squared_factor[i, zero_idx[k]].sum())
+                          for k in range(indicator.shape[0]))                    # :112-114
+                u[i] = Xty / (XtX + lam)                                         # :117
+                resid = resid - u[i] * np.outer(z, c_factor[i, :])               # :118
+            if np.sum(np.abs(pre - u)) < 1e-1:                                   # :122
+                break
+    elif tuning == 0:
+        Xty = c_factor @ data.T @ z                                              # :128
+        XtX = (z @ z) * gram + lam * np.eye(K)                                   # :129-130
+        u = np.linalg.solve(XtX, Xty)                                            # :131
+    else:
+        raise ValueError("Parameter tuning should be either 0 or 1!")
+    return u
+
+
 # -- src/optimize.cpp:200-253 ---------------------------------------------------
 def optimize_col(data, indicator, row_factor, c_factor, lam, alpha, tuning, tol, seed=0, it=0, order_mode=0,
                  max_sweeps=10000, gene_offset=0):
@@ -182,7 +213,7 @@ def compute_loss(cfd, column_factor, lam1, lam2, alpha, sum_residual):
 # -- src/optimize.cpp:255-422 ---------------------------------------------------
 def optimize(data, cfd_factors, column_factor, cfd_indicators, train_indicator, test_indicator, lam1=1.0, lam2=1.0,
              alpha=0.1, tuning=1, global_tol=1e-10, sub_tol=1e-5, max_iter=10000, seed=0, order_mode=0,
-             max_sweeps=10000):
+             max_sweeps=10000, ctns_confounder=None):
     data = np.asarray(data, float)
     n, p = data.shape
     cfd = [np.array(a, float).copy() for a in cfd_factors]
@@ -196,7 +227,11 @@ def optimize(data, cfd_factors, column_factor, cfd_indicators, train_indicator, 
         for k, lv in enumerate(levels):
             z[ind[:, i] == lv, k] = 1.0
         Z.append(z)
-    row_factor = sum(cfd[i][ind[:, i] - 1, :] for i in range(c))     # :281-291
+    ctns = None if ctns_confounder is None else np.asarray(ctns_confounder, float).reshape(n, -1)
+    def rows():
+        rf = sum(cfd[i][ind[:, i] - 1, :] for i in range(c))
+        return rf if ctns is None else rf + ctns @ cfd[c]                # :289,372
+    row_factor = rows()                                              # :281-291
     residual = data - row_factor @ Cf                                # :320-321
     s, tr, te = evaluate(residual, train_indicator, test_indicator, tuning)   # :322
     loss, comps = compute_loss(cfd, Cf, lam1, lam2, alpha, s)        # :323
@@ -209,9 +244,16 @@ def optimize(data, cfd_factors, column_factor, cfd_indicators, train_indicator, 
         for i in range(c):                                           # :335
             residual = residual + Z[i] @ cfd[i] @ Cf                 # :338
             cfd[i] = optimize_row(residual, train_indicator, cfd[i], Cf, ind[:, i], gram, lam1, tuning)   # :339
-            if i != c - 1:
+            if i != c - 1 or ctns is not None:
                 residual = residual - Z[i] @ cfd[i] @ Cf             # :353-355
-        row_factor = sum(Z[i] @ cfd[i] for i in range(c))            # :365-369
+        if ctns is not None:                                         # :340-351
+            for j in range(ctns.shape[1]):
+                residual = residual + np.outer(ctns[:, j], cfd[c][j, :] @ Cf)        # :344
+                cfd[c][j, :] = optimize_continuous_v2(residual, train_indicator, cfd[c][j, :], Cf, ctns[:, j], gram,
+                                                      lam1, tuning)                  # :345-346
+                if j != ctns.shape[1] - 1:
+                    residual = residual - np.outer(ctns[:, j], cfd[c][j, :] @ Cf)    # :347-349
+        row_factor = rows()                                          # :365-373
         Cf, sw = optimize_col(data, train_indicator, row_factor, Cf, lam2, alpha, tuning, sub_tol * decay, seed, it,
                               order_mode, max_sweeps)                # :376
         total_sweeps += sw

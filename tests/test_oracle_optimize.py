@@ -132,3 +132,40 @@ def test_bad_level_ids_rejected(oracle):
     lev[0, 0] = 0
     with pytest.raises(RuntimeError):
         oracle.optimize(w.X, lev, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, 1, 1, 0.1, max_iter=1)
+
+
+def _ctns(w, m, seed=5):
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((w.n, m))
+    U0 = np.asfortranarray(rng.normal(0.0, 0.001, size=(m, w.K)))
+    return np.asfortranarray(Z), U0
+
+
+@pytest.mark.parametrize("tuning", [0, 1])
+def test_optimize_continuous_matches_numpy(oracle, tuning):
+    # optimize_continuous_v2 (src/optimize.cpp:76-137)
+    w = W.small(n=30, p=40, with_na=True)
+    A, C = _rand_factors(w, 6)
+    rng = np.random.default_rng(1)
+    z = rng.standard_normal(w.n)
+    u = rng.standard_normal(w.K) * 0.2
+    data = w.X - _R(w, A) @ C                                    # some residual with u's part "added back"
+    gram = C @ C.T
+    uc = oracle.optimize_continuous(data, w.M_train, u, C, z, gram, 1.3, tuning)
+    un = NO.optimize_continuous_v2(data, w.M_train, u, C, z, gram, 1.3, tuning)
+    np.testing.assert_allclose(uc, un, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(tuning=0), dict(with_na=True)])
+def test_optimize_with_continuous_matches_numpy(oracle, kw):
+    w = W.small(n=36, p=48, **kw)
+    Z, U0 = _ctns(w, 2)
+    res_c = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + [U0], w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                            tuning=w.tuning, max_iter=11, seed=42, ctns=Z)
+    res_n = NO.optimize(w.X, w.A0 + [U0], w.C0, w.levels, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=w.tuning,
+                        max_iter=11, seed=42, ctns_confounder=Z)
+    assert res_c["iters"] == res_n["iters"] and res_c["total_sweeps"] == res_n["total_sweeps"]
+    np.testing.assert_allclose(res_c["traj"], res_n["traj"], rtol=1e-9, atol=1e-12, equal_nan=True)
+    for a, b in zip(res_c["row_matrices"], res_n["row_matrices"]):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(res_c["column_factor"], res_n["column_factor"], rtol=1e-8, atol=1e-10)
