@@ -32,7 +32,7 @@ extern "C" {
 #define INSIDER_ERR_ALLOC 3      /* host or device allocation failed */
 #define INSIDER_ERR_HIP 4        /* HIP runtime error (message has the call) */
 #define INSIDER_ERR_NO_DEVICE 5  /* no HIP device / extension unusable: no fallback exists */
-#define INSIDER_ERR_UNSUPPORTED 6 /* e.g. continuous covariates (inc_continuous = 1), K > 63 */
+#define INSIDER_ERR_UNSUPPORTED 6 /* K > 63, n or p >= 2^23, ... */
 #define INSIDER_ERR_COMM 7       /* the all-reduce callback reported failure */
 
 /* Largest latent dimension the kernels support (K + 1 augmented column <= 64). */
@@ -71,6 +71,12 @@ int insider_hip_device_count(void);
  */
 int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *levels, int c, const int32_t *n_levels,
                        const uint8_t *M_train, const uint8_t *M_test, int device, insider_hip_handle **out);
+/* The same with continuous covariates (ctns_confounder of R/insider.R:48-51; src/optimize.cpp:276-291): ctns is
+ * n x m column-major fp64 (NULL / 0 for none).  insider_hip_optimize() must then be called with inc_continuous = 1
+ * and c + 1 row-factor pointers, the last one m x K column-major (cfd_matrices(cfd_num-1), :281-291). */
+int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *levels, int c, const int32_t *n_levels,
+                          const double *ctns, int m, const uint8_t *M_train, const uint8_t *M_test, int device,
+                          insider_hip_handle **out);
 void insider_hip_destroy(insider_hip_handle *h);
 
 /* Gene-axis sharding: this handle holds genes [gene_offset, gene_offset + p) of the global
@@ -97,7 +103,10 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
  *   out_*        train_rmse, test_rmse (NaN when tuning = 0: uninitialised in the reference, :264), loss
  *   traj         optional, traj_cap rows of INSIDER_TRAJ_STRIDE doubles; out_traj_rows rows written
  *   out_iters    value of `iter` when the loop ended
- * inc_continuous = 1 (ctns_confounder) is not supported yet: pass 0 (INSIDER_ERR_UNSUPPORTED otherwise).
+ * inc_continuous must be 1 exactly when the handle was created with continuous covariates
+ * (insider_hip_create_ex); each column j is then updated after the categorical covariates by
+ * optimize_continuous_v2 (src/optimize.cpp:76-137,340-351): cyclic scalar CD to sum|du| < 0.1 (tuning = 1) or one
+ * ridge solve (tuning = 0).  The one-shot form takes categorical covariates only.
  */
 int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K,
                          double lambda1, double lambda2, double alpha, int tuning, double global_tol, double sub_tol,

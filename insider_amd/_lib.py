@@ -20,6 +20,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 # every symbol include/insider_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "insider_hip_version", "insider_hip_last_error", "insider_hip_device_count", "insider_hip_create",
+    "insider_hip_create_ex",
     "insider_hip_destroy", "insider_hip_set_shard", "insider_hip_set_option", "insider_hip_optimize",
     "insider_hip_optimize_oneshot", "insider_hip_strong_cd", "insider_hip_masked_gram_cols",
     "insider_hip_masked_gram_rows", "insider_hip_get_profile", "insider_hip_get_sweeps", "insider_hip_last_cd_ms",
@@ -50,6 +51,8 @@ def load():
     lib.insider_hip_device_count.restype = C.c_int
     lib.insider_hip_create.argtypes = [dp, C.c_int64, C.c_int64, i32p, C.c_int, i32p, u8p, u8p, C.c_int,
                                        C.POINTER(C.c_void_p)]
+    lib.insider_hip_create_ex.argtypes = [dp, C.c_int64, C.c_int64, i32p, C.c_int, i32p, dp, C.c_int, u8p, u8p, C.c_int,
+                                          C.POINTER(C.c_void_p)]
     lib.insider_hip_destroy.argtypes = [C.c_void_p]
     lib.insider_hip_destroy.restype = None
     lib.insider_hip_set_shard.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]

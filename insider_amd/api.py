@@ -25,7 +25,8 @@ DEFAULT_SEED = 0x1D5EED
 class InsiderData:
     """A data set resident in HBM (insider_hip_create). Reused across optimize() calls, e.g. by tune()'s grid."""
 
-    def __init__(self, data, cfd_indicators, train_indicator, test_indicator, device=0, n_levels=None):
+    def __init__(self, data, cfd_indicators, train_indicator, test_indicator, device=0, n_levels=None,
+                 ctns_confounder=None):
         lib = _lib.load()
         X = _lib.f64(data)
         n, p = X.shape
@@ -42,9 +43,15 @@ class InsiderData:
         self.n, self.p, self.c = n, p, c
         self.n_levels = n_levels
         self._h = C.c_void_p()
-        _lib.check(lib.insider_hip_create(_lib.ptr(X), n, p, _lib.ptr(lev, C.c_int32), c, _lib.ptr(n_levels, C.c_int32),
-                                          _lib.ptr(Mtr, C.c_uint8), _lib.ptr(Mte, C.c_uint8), int(device),
-                                          C.byref(self._h)))
+        if ctns_confounder is not None:
+            Z = _lib.f64(np.asarray(ctns_confounder, dtype=np.float64).reshape(n, -1))
+            self.m = Z.shape[1]
+            zp = _lib.ptr(Z)
+        else:
+            self.m, zp = 0, None
+        _lib.check(lib.insider_hip_create_ex(_lib.ptr(X), n, p, _lib.ptr(lev, C.c_int32), c,
+                                             _lib.ptr(n_levels, C.c_int32), zp, self.m, _lib.ptr(Mtr, C.c_uint8),
+                                             _lib.ptr(Mte, C.c_uint8), int(device), C.byref(self._h)))
         self._cb = None  # keeps the ctypes callback alive
 
     def set_option(self, name, value):
@@ -71,16 +78,19 @@ class InsiderData:
         lib = _lib.load()
         K = int(latent_dim)
         A = []
+        shapes = [int(L) for L in self.n_levels] + ([self.m] if inc_continuous else [])
+        if len(cfd_factors) != len(shapes):
+            raise InsiderError(_lib.ERR_ARG, f"expected {len(shapes)} row-factor matrices, got {len(cfd_factors)}")
         for i, a in enumerate(cfd_factors):
             a = np.asarray(a)
-            if a.shape != (int(self.n_levels[i]), K):
-                raise InsiderError(_lib.ERR_ARG, f"cfd_factors[{i}] must be {int(self.n_levels[i])} x {K}")
+            if a.shape != (shapes[i], K):
+                raise InsiderError(_lib.ERR_ARG, f"cfd_factors[{i}] must be {shapes[i]} x {K}")
             A.append(a if (a.dtype == np.float64 and a.flags.f_contiguous) else _lib.f64(a).copy(order="F"))
         Cm = np.asarray(column_factor)
         if Cm.shape != (K, self.p):
             raise InsiderError(_lib.ERR_ARG, f"column_factor must be {K} x {self.p}")
         Cw = Cm if (Cm.dtype == np.float64 and Cm.flags.f_contiguous) else _lib.f64(Cm).copy(order="F")
-        Aptrs = (C.POINTER(C.c_double) * self.c)(*[_lib.ptr(a) for a in A])
+        Aptrs = (C.POINTER(C.c_double) * len(A))(*[_lib.ptr(a) for a in A])
         traj = np.full((traj_cap, _lib.TRAJ_STRIDE), np.nan)
         tr, te, lo = C.c_double(), C.c_double(), C.c_double()
         rows, iters = C.c_int(), C.c_int()
@@ -154,7 +164,8 @@ def optimize(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, 
         raise InsiderError(_lib.ERR_ARG, "Parameter tuning should be either 0 or 1!")
     if inc_continuous not in (0, 1):
         raise InsiderError(_lib.ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.")
-    ds = InsiderData(data, cfd_indicators, train_indicator, test_indicator, device=device)
+    ds = InsiderData(data, cfd_indicators, train_indicator, test_indicator, device=device,
+                     ctns_confounder=ctns_confounder if inc_continuous == 1 else None)
     try:
         return ds.optimize(cfd_factors, column_factor, latent_dim, lambda1, lambda2, alpha, tuning, global_tol, sub_tol,
                            max_iter, seed, inc_continuous)
@@ -273,7 +284,8 @@ def _resident(obj, which):
             tr, te = obj["train_indicator"], obj["test_indicator"]
         else:  # R/insider.R:207-208: indicator = train + test, "test" = NA mask
             tr, te = obj["train_indicator"] + obj["test_indicator"], obj["na_indicator"]
-        obj[key] = InsiderData(obj["data"], obj["confounder"], tr, te, device=obj.get("device", 0))
+        obj[key] = InsiderData(obj["data"], obj["confounder"], tr, te, device=obj.get("device", 0),
+                               ctns_confounder=obj["ctns_confounder"] if obj["inc_continuous"] == 1 else None)
     return obj[key]
 
 

@@ -59,6 +59,7 @@ struct CovTables {   // per covariate, device
     int L = 0, nchunks = 0;
     int *chunk_level = nullptr, *chunk_begin = nullptr, *chunk_end = nullptr, *lvl_chunk_ptr = nullptr;
 };
+// continuous columns share one table: a single pseudo-level whose members are all samples, in 16-sample chunks
 
 constexpr int LEVEL_CHUNK = 16;
 
@@ -68,13 +69,18 @@ struct insider_hip_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t n = 0, p = 0, ldn = 0, ldp = 0;
-    int c = 0, SL = 0, SLP = 0;
+    int c = 0, SL = 0, SLP = 0;   // SL: rows of the stacked row factors = all levels of all covariates + m
+    int m = 0, SLcat = 0;          // continuous covariates (columns of ctns_confounder) and the categorical level total
+    double *Zc = nullptr;          // m x n
+    int *one_count = nullptr;      // a "member count" of 1 for the single pseudo-level of a continuous column
     std::vector<int> n_levels, lvl_off;   // lvl_off has c + 1 entries
     // data-set state (device)
     double *X = nullptr, *Xt = nullptr;
     uint8_t *codes = nullptr, *codes_t = nullptr;
     int *lev = nullptr, *lvl_off_d = nullptr, *members_all = nullptr, *lvl_ptr_all = nullptr, *lvl_count_all = nullptr;
     std::vector<CovTables> cov;
+    CovTables cont;                // chunk tables shared by every continuous column
+    int *ident_members = nullptr;  // 0..n-1
     int max_chunks = 0, max_L = 0;
     double *S = nullptr, *yy_train = nullptr, *yy_all = nullptr;
     double cnt_train = 0, cnt_test = 0;
@@ -167,7 +173,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->stat_col, (size_t)h->p * STAT))) return rc;
     if ((rc = dmalloc(&h->gram_part, (size_t)std::max(h->gram_blocks_p, h->gram_blocks_n) * KP * KP))) return rc;
     if ((rc = dmalloc(&h->sc_part, (size_t)h->sc_blocks * h->SL * KP))) return rc;
-    if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP)))) return rc;
+    if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP + 2)))) return rc;
     if ((rc = dmalloc(&h->eq, (size_t)h->max_L * (KP * KP + KP)))) return rc;
     if ((rc = dmalloc(&h->sse_train, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sse_test, (size_t)h->p))) return rc;
@@ -241,13 +247,21 @@ int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *ou
     return INSIDER_OK;
 }
 
+int launch_build_R(insider_hip_handle *h)
+{
+    hipLaunchKernelGGL(k_build_R, dim3(cdiv(h->n * h->KP, 256)), dim3(256), 0, h->stream, (const int *)h->lev,
+                       (const int *)h->lvl_off_d, h->c, (int)h->n, (const double *)h->Astack, h->KP,
+                       (const double *)h->Zc, h->m, h->SLcat, h->R);
+    KCHECK();
+    return INSIDER_OK;
+}
+
 // R, R'R and Qfull from the current row factors (src/optimize.cpp:365-369 and the Xty of :222,235 via level sums)
 int phase_R(insider_hip_handle *h)
 {
-    hipLaunchKernelGGL(k_build_R, dim3(cdiv(h->n * h->KP, 256)), dim3(256), 0, h->stream, h->lev, h->lvl_off_d, h->c,
-                       (int)h->n, h->Astack, h->KP, h->R);
-    KCHECK();
-    int rc = launch_gram(h, h->R, h->n, h->RtR);
+    int rc = launch_build_R(h);
+    if (rc) return rc;
+    rc = launch_gram(h, h->R, h->n, h->RtR);
     if (rc) return rc;
     hipLaunchKernelGGL(k_qfull, dim3(cdiv(h->p, 256 / h->KP)), dim3(256), 0, h->stream, (const double *)h->S, h->SL,
                        h->SLP, (const double *)h->Astack, h->KP, (int)h->p, h->Qfull);
@@ -419,36 +433,39 @@ int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
     return INSIDER_OK;
 }
 
-// one covariate's row update (optimize_row, src/optimize.cpp:139-198)
-int row_update(insider_hip_handle *h, int i, int masked, double lambda1)
+// one covariate's row update: categorical covariate i (optimize_row, src/optimize.cpp:139-198), or continuous
+// column j (optimize_continuous_v2, :76-137) when cont_col >= 0
+int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double lambda1)
 {
-    const CovTables &ct = h->cov[i];
+    const bool cont = cont_col >= 0;
+    const CovTables &ct = cont ? h->cont : h->cov[i];
+    const int row0 = cont ? h->SLcat + cont_col : h->lvl_off[i];   // first row of this covariate in Astack / SC
     LevelArgs la;
     la.stat = h->stat;
     la.nseg = h->nseg;
     la.n = (int)h->n;
     la.K = h->K;
     la.masked = masked;
+    la.R = h->R;
     la.lev = h->lev;
     la.lvl_off = h->lvl_off_d;
-    la.c = h->c;
-    la.cov = i;
-    la.chunk_level = ct.chunk_level;
+    la.cov = cont ? -1 : i;
+    la.own_row = row0;
+    la.weights = cont ? h->Zc + (size_t)cont_col * h->n : nullptr;
     la.chunk_begin = ct.chunk_begin;
     la.chunk_end = ct.chunk_end;
-    la.members = h->members_all + (size_t)i * h->n;
+    la.members = cont ? h->ident_members : h->members_all + (size_t)i * h->n;
     la.nchunks = ct.nchunks;
     la.Astack = h->Astack;
     la.part = h->lvl_part;
     LevelReduceArgs ra;
     ra.part = h->lvl_part;
     ra.lvl_chunk_ptr = ct.lvl_chunk_ptr;
-    ra.lvl_count = h->lvl_count_all + h->lvl_off[i];
     ra.L = ct.L;
     ra.K = h->K;
     ra.CCt = h->CCt;
     ra.SC = h->SC;
-    ra.sc_off = h->lvl_off[i];
+    ra.sc_off = row0;
     ra.eq = h->eq;
     NB_DISPATCH(h->NB, {
         (void)WPB_;
@@ -458,14 +475,23 @@ int row_update(insider_hip_handle *h, int i, int masked, double lambda1)
     KCHECK();
     int rc = do_allreduce(h, h->eq, (int64_t)ct.L * (h->KP * h->KP + h->KP));
     if (rc) return rc;
-    NB_DISPATCH(h->NB, {
-        (void)WPB_;
-        hipLaunchKernelGGL((k_level_solve<NB_>), dim3(ct.L), dim3(64), 0, h->stream, h->eq,
-                           h->lvl_count_all + h->lvl_off[i], ct.L, h->K, lambda1,
-                           h->Astack + (size_t)h->lvl_off[i] * h->KP, h->failflag);
-    });
+    if (cont && masked) {
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            hipLaunchKernelGGL((k_cont_cd<NB_>), dim3(1), dim3(64), 0, h->stream, (const double *)h->eq, h->K, lambda1,
+                               h->Astack + (size_t)row0 * h->KP);
+        });
+    } else {
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            hipLaunchKernelGGL((k_level_solve<NB_>), dim3(ct.L), dim3(64), 0, h->stream, (const double *)h->eq,
+                               (const int *)(cont ? h->one_count : h->lvl_count_all + h->lvl_off[i]), ct.L, h->K, lambda1,
+                               h->Astack + (size_t)row0 * h->KP, h->failflag);
+        });
+    }
     KCHECK();
-    return INSIDER_OK;
+    // the next covariate's Gauss-Seidel residual sees this update (:353-355, :347-349)
+    return launch_build_R(h);
 }
 
 struct LossOut {
@@ -544,7 +570,8 @@ void insider_hip_destroy(insider_hip_handle *h)
     free_workspace(h);
     void *ptrs[] = {h->X, h->Xt, h->codes, h->codes_t, h->lev, h->lvl_off_d, h->members_all, h->lvl_ptr_all,
                     h->lvl_count_all, h->S, h->yy_train, h->yy_all, h->col_ptr, h->row_ptr, h->col_idx, h->row_idx,
-                    h->col_val, h->row_val};
+                    h->col_val, h->row_val, h->Zc, h->one_count, h->ident_members, h->cont.chunk_begin, h->cont.chunk_end,
+                    h->cont.lvl_chunk_ptr};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &ct : h->cov) {
         if (ct.chunk_level) (void)hipFree(ct.chunk_level);
@@ -559,6 +586,14 @@ void insider_hip_destroy(insider_hip_handle *h)
 int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *levels, int c, const int32_t *n_levels,
                        const uint8_t *M_train, const uint8_t *M_test, int device, insider_hip_handle **out)
 {
+    return insider_hip_create_ex(X, n, p, levels, c, n_levels, nullptr, 0, M_train, M_test, device, out);
+}
+
+int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *levels, int c, const int32_t *n_levels,
+                          const double *ctns, int m, const uint8_t *M_train, const uint8_t *M_test, int device,
+                          insider_hip_handle **out)
+{
+    if (m < 0 || (m > 0 && !ctns)) { if (out) *out = nullptr; return fail(INSIDER_ERR_ARG, "bad continuous covariates"); }
     if (!out) return fail(INSIDER_ERR_ARG, "out is null");
     *out = nullptr;
     if (!X || !levels || !n_levels || !M_train || !M_test) return fail(INSIDER_ERR_ARG, "null input");
@@ -587,7 +622,9 @@ int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *lev
     h->n_levels.assign(n_levels, n_levels + c);
     h->lvl_off.assign(c + 1, 0);
     for (int i = 0; i < c; ++i) h->lvl_off[i + 1] = h->lvl_off[i] + n_levels[i];
-    h->SL = h->lvl_off[c];
+    h->m = m;
+    h->SLcat = h->lvl_off[c];
+    h->SL = h->SLcat + m;
     h->SLP = (int)round_up(h->SL, 2);
     int rc = INSIDER_OK;
 #define CR(x) do { rc = (x); if (rc) { insider_hip_destroy(h); return rc; } } while (0)
@@ -628,7 +665,7 @@ int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *lev
     }
     // ---- level tables ------------------------------------------------------------------------------------------
     {
-        std::vector<int> lev0((size_t)c * n), members((size_t)c * n), lvl_ptr((size_t)h->SL + c), lvl_count(h->SL);
+        std::vector<int> lev0((size_t)c * n), members((size_t)c * n), lvl_ptr((size_t)h->SLcat + c), lvl_count(h->SLcat);
         h->cov.resize(c);
         for (int i = 0; i < c; ++i) {
             const int L = n_levels[i];
@@ -679,6 +716,30 @@ int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *lev
         CH(hipMemcpy(h->lvl_count_all, lvl_count.data(), lvl_count.size() * sizeof(int), hipMemcpyHostToDevice));
         CH(hipMemcpy(h->lvl_off_d, h->lvl_off.data(), h->lvl_off.size() * sizeof(int), hipMemcpyHostToDevice));
     }
+    // ---- continuous covariates: one pseudo-level whose members are all samples, weighted by z ----------------------------
+    if (m > 0) {
+        CR(dmalloc(&h->Zc, (size_t)m * n));
+        CH(hipMemcpy(h->Zc, ctns, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice));   // n x m column-major == m x n rows
+        std::vector<int> ident(n), cb, ce, lcp(2, 0);
+        for (int64_t r = 0; r < n; ++r) ident[r] = (int)r;
+        for (int64_t b0 = 0; b0 < n; b0 += LEVEL_CHUNK) { cb.push_back((int)b0); ce.push_back((int)std::min<int64_t>(b0 + LEVEL_CHUNK, n)); }
+        lcp[1] = (int)cb.size();
+        h->cont.L = 1;
+        h->cont.nchunks = (int)cb.size();
+        h->max_chunks = std::max(h->max_chunks, h->cont.nchunks);
+        h->max_L = std::max(h->max_L, 1);
+        CR(dmalloc(&h->ident_members, ident.size()));
+        CR(dmalloc(&h->cont.chunk_begin, cb.size()));
+        CR(dmalloc(&h->cont.chunk_end, ce.size()));
+        CR(dmalloc(&h->cont.lvl_chunk_ptr, lcp.size()));
+        CR(dmalloc(&h->one_count, 1));
+        const int one = 1;
+        CH(hipMemcpy(h->ident_members, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->cont.chunk_begin, cb.data(), cb.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->cont.chunk_end, ce.data(), ce.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->cont.lvl_chunk_ptr, lcp.data(), lcp.size() * sizeof(int), hipMemcpyHostToDevice));
+        CH(hipMemcpy(h->one_count, &one, sizeof(int), hipMemcpyHostToDevice));
+    }
     // ---- factor-independent statistics -----------------------------------------------------------------------------
     CR(dmalloc(&h->S, (size_t)p * h->SLP));
     CR(dmalloc(&h->yy_train, (size_t)p));
@@ -690,9 +751,12 @@ int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *lev
         CH(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), h->stream));
         hipLaunchKernelGGL(k_line_sumsq, dim3(cdiv(p, 4)), dim3(256), 0, h->stream, (const double *)h->X,
                            (const uint8_t *)h->codes, h->ldn, (int)n, (int)p, h->yy_train, h->yy_all, cnt);
-        hipLaunchKernelGGL(k_level_sums, dim3(cdiv(p * h->SL, 256)), dim3(256), 0, h->stream, (const double *)h->X,
+        hipLaunchKernelGGL(k_level_sums, dim3(cdiv(p * h->SLcat, 256)), dim3(256), 0, h->stream, (const double *)h->X,
                            h->ldn, (int)p, (const int *)h->members_all, (const int *)h->lvl_ptr_all,
-                           (const int *)h->lvl_off_d, c, (int)n, h->SL, h->SLP, h->S);
+                           (const int *)h->lvl_off_d, c, (int)n, h->SLcat, h->SLP, h->S);
+        if (m > 0)
+            hipLaunchKernelGGL(k_cont_sums, dim3(cdiv(p * m, 256)), dim3(256), 0, h->stream, (const double *)h->X, h->ldn,
+                               (int)p, (const double *)h->Zc, m, (int)n, h->SLcat, h->SLP, h->S);
         CH(hipGetLastError());
         unsigned long long hc[2];
         CH(hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
@@ -785,8 +849,11 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         return fail(INSIDER_ERR_ARG, "Parameter tuning should be either 0 or 1!");
     if (inc_continuous != 0 && inc_continuous != 1)   // src/optimize.cpp:270-272
         return fail(INSIDER_ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.");
-    if (inc_continuous == 1) return fail(INSIDER_ERR_UNSUPPORTED, "continuous covariates are not supported yet");
-    for (int i = 0; i < h->c; ++i) if (!A[i]) return fail(INSIDER_ERR_ARG, "null row factor");
+    if (inc_continuous == 1 && h->m == 0)
+        return fail(INSIDER_ERR_ARG, "inc_continuous = 1 needs a handle created with ctns_confounder (insider_hip_create_ex)");
+    if (inc_continuous == 0 && h->m > 0)
+        return fail(INSIDER_ERR_ARG, "this handle carries continuous covariates: pass inc_continuous = 1");
+    for (int i = 0; i < h->c + (h->m > 0 ? 1 : 0); ++i) if (!A[i]) return fail(INSIDER_ERR_ARG, "null row factor");
     HIPCHECK(hipSetDevice(h->device));
     int rc = ensure_workspace(h, K);
     if (rc) return rc;
@@ -802,6 +869,13 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
                            h->Astack + (size_t)h->lvl_off[i] * KP);
         KCHECK();
         HIPCHECK(hipStreamSynchronize(h->stream));   // stage is reused
+    }
+    if (h->m > 0) {
+        HIPCHECK(hipMemcpyAsync(h->stage, A[h->c], (size_t)h->m * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_pack_A, dim3(cdiv(h->m * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, h->m, K,
+                           KP, h->Astack + (size_t)h->SLcat * KP);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));
     }
     HIPCHECK(hipMemcpyAsync(h->stage, C, (size_t)h->p * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(h->p * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, h->p, K,
@@ -848,7 +922,10 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         }
         if (masked) if ((rc = launch_row_stats(h, true))) return rc;
         for (int i = 0; i < h->c; ++i)
-            if ((rc = row_update(h, i, masked, lambda1))) return rc;                            // :339
+            if ((rc = row_update(h, i, -1, masked, lambda1))) return rc;                        // :339
+        if (inc_continuous)
+            for (int j = 0; j < h->m; ++j)
+                if ((rc = row_update(h, 0, j, masked, lambda1))) return rc;                     // :340-351
         // ---- column step (:365-378) -------------------------------------------------------------------------------
         if ((rc = phase_R(h))) return rc;
         const int checkpoint = iter % 10 == 0;
@@ -891,6 +968,13 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
                            (const double *)(h->Astack + (size_t)h->lvl_off[i] * KP), L, K, KP, h->stage);
         KCHECK();
         HIPCHECK(hipMemcpyAsync(A[i], h->stage, (size_t)L * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    if (h->m > 0) {
+        hipLaunchKernelGGL(k_unpack_A, dim3(cdiv(h->m * K, 256)), dim3(256), 0, h->stream,
+                           (const double *)(h->Astack + (size_t)h->SLcat * KP), h->m, K, KP, h->stage);
+        KCHECK();
+        HIPCHECK(hipMemcpyAsync(A[h->c], h->stage, (size_t)h->m * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipStreamSynchronize(h->stream));
     }
     hipLaunchKernelGGL(k_unpack_rows, dim3(cdiv(h->p * K, 256)), dim3(256), 0, h->stream, (const double *)h->C, h->p, K,

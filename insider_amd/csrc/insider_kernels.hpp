@@ -805,15 +805,31 @@ k_cd_batch(const double *__restrict__ XtX, const double *__restrict__ Xty, const
 // ---------------------------------------------------------------------------------------------
 
 // R[r][:] = sum_i Astack[off_i + level_i(r)][:]   (src/optimize.cpp:365-369), rows of pitch KP
+// (+ sum_j z_rj U_j for the continuous covariates, src/optimize.cpp:289,372: U = rows SLcat.. of Astack)
 __global__ void k_build_R(const int *__restrict__ lev /*c x n, 0-based*/, const int *__restrict__ lvl_off, int c, int n,
-                          const double *__restrict__ Astack, int KP, double *__restrict__ R)
+                          const double *__restrict__ Astack, int KP, const double *__restrict__ Zc /*m x n*/, int m,
+                          int SLcat, double *__restrict__ R)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)n * KP) return;
     const int r = (int)(t / KP), k = (int)(t % KP);
     double s = 0.0;
     for (int i = 0; i < c; ++i) s += Astack[(size_t)(lvl_off[i] + lev[(size_t)i * n + r]) * KP + k];
+    for (int j = 0; j < m; ++j) s += Zc[(size_t)j * n + r] * Astack[(size_t)(SLcat + j) * KP + k];
     R[t] = s;
+}
+
+// S[gene][SLcat + j] = sum_r z_rj x_r,gene   (continuous covariates: "levels" with real-valued membership)
+__global__ void __launch_bounds__(256) k_cont_sums(const double *__restrict__ vals, int64_t pitch, int p,
+                                                   const double *__restrict__ Zc, int m, int n, int SLcat, int SLP,
+                                                   double *__restrict__ S)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)p * m) return;
+    const int g = (int)(t / m), j = (int)(t % m);
+    double s = 0.0;
+    for (int r = 0; r < n; ++r) s += Zc[(size_t)j * n + r] * vals[(size_t)g * pitch + r];
+    S[(size_t)g * SLP + SLcat + j] = s;
 }
 
 // Partial Gram of a tall matrix F (rows x KP): part[blk] = sum over the block's rows of f f'  (KP x KP)
@@ -929,16 +945,18 @@ __global__ void __launch_bounds__(256) k_sc_partial(const double *__restrict__ S
 struct LevelArgs {
     const double *stat;      // [nseg][n][STAT] complement statistics (masked) — may be null when !masked
     int nseg, n, K, masked;
+    const double *R;         // n x KP: the CURRENT row factor rows (all covariates)
     const int *lev;          // c x n, 0-based
     const int *lvl_off;      // c + 1 prefix offsets into the stacked levels
-    int c, cov;              // updating covariate
-    const int *chunk_level;  // per chunk: level (0-based within the covariate)
+    int cov;                 // updating categorical covariate, or -1 for a continuous column
+    int own_row;             // continuous column: its row of Astack
+    const double *weights;   // continuous column: z_r per sample (null: membership weight 1)
     const int *chunk_begin;  // per chunk: range into members
     const int *chunk_end;
     const int *members;      // sample ids sorted by level (this covariate)
     int nchunks;
     const double *Astack;    // SL x KP
-    double *part;            // [nchunks][STAT + 2*KP]: blocks of sum Hc, then v = sum(Hc s - bc), then ssum = sum s
+    double *part;            // [nchunks][STAT + 2*KP + 2]: sum w^2 Hc | v = sum w (Hc s - bc) | sum w s | sum w^2
 };
 
 template <int NB>
@@ -955,14 +973,18 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
     d4 hsum[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) hsum[b] = d4{0.0, 0.0, 0.0, 0.0};
-    double v = 0.0, ssum = 0.0;
+    double v = 0.0, ssum = 0.0, w2sum = 0.0;
     for (int mi = a.chunk_begin[ch]; mi < a.chunk_end[ch]; ++mi) {
         const int r = a.members[mi];
+        const double w = a.weights ? a.weights[r] : 1.0;
+        // s_r: everything but this covariate's own contribution (the Gauss-Seidel residual of :338,344 is x_r - s_r'C)
         double s = 0.0;
-        if (valid)
-            for (int m = 0; m < a.c; ++m)
-                if (m != a.cov) s += a.Astack[(size_t)(a.lvl_off[m] + a.lev[(size_t)m * a.n + r]) * KP + lane];
-        ssum += s;
+        if (valid) {
+            const int own = a.cov >= 0 ? a.lvl_off[a.cov] + a.lev[(size_t)a.cov * a.n + r] : a.own_row;
+            s = a.R[(size_t)r * KP + lane] - w * a.Astack[(size_t)own * KP + lane];
+        }
+        ssum += w * s;
+        w2sum += w * w;
         if (a.masked) {
             d4 h[NBLK];
 #pragma unroll
@@ -981,19 +1003,20 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
             if (valid) {
                 double y = -s_H[(KP - 1) * KP + lane];     // - bc_r (the x slot is the last one of the padded row)
                 for (int b = 0; b < K; ++b) y += s_H[lane * KP + b] * s_s[b];
-                v += y;
+                v += w * y;
             }
-            // the augmented row/column K (bc, sum x^2) must not enter the Gram sum
+            const double w2 = w * w;
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) hsum[b] += h[b];
+            for (int b = 0; b < NBLK; ++b) hsum[b] += w2 * h[b];
         }
     }
-    double *out = a.part + (size_t)ch * (STAT + 2 * KP);
+    double *out = a.part + (size_t)ch * (STAT + 2 * KP + 2);
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[b * 256 + (sub + 4 * q) * 16 + c16] = hsum[b][q];
     if (lane < KP) { out[STAT + lane] = valid ? v : 0.0; out[STAT + KP + lane] = valid ? ssum : 0.0; }
+    if (lane == 0) { out[STAT + 2 * KP] = w2sum; out[STAT + 2 * KP + 1] = 0.0; }
 }
 
 // Stage 2 (one wave per level): sum the level's chunk partials in fixed order and form this rank's share of
@@ -1001,7 +1024,6 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
 struct LevelReduceArgs {
     const double *part;
     const int *lvl_chunk_ptr;   // per level: chunk range
-    const int *lvl_count;       // per level: member count
     int L, K;
     const double *CCt;          // KP x KP (this rank's gene slab)
     const double *SC;           // [SL][KP]: (S C') rows; this covariate starts at sc_off
@@ -1023,9 +1045,10 @@ __global__ void __launch_bounds__(64) k_level_reduce(LevelReduceArgs a)
     d4 h[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) h[b] = d4{0.0, 0.0, 0.0, 0.0};
-    double v = 0.0, ssum = 0.0;
+    double v = 0.0, ssum = 0.0, cnt = 0.0;
     for (int ch = a.lvl_chunk_ptr[l]; ch < a.lvl_chunk_ptr[l + 1]; ++ch) {
-        const double *src = a.part + (size_t)ch * (STAT + 2 * KP);
+        const double *src = a.part + (size_t)ch * (STAT + 2 * KP + 2);
+        cnt += src[STAT + 2 * KP];
 #pragma unroll
         for (int b = 0; b < NBLK; ++b)
 #pragma unroll
@@ -1035,7 +1058,6 @@ __global__ void __launch_bounds__(64) k_level_reduce(LevelReduceArgs a)
     acc_to_lds<NB>(h, s_H, lane);
     if (lane < KP) s_s[lane] = ssum;
     wave_sync();
-    const double cnt = (double)a.lvl_count[l];
     double *eq = a.eq + (size_t)l * (KP * KP + KP);
     for (int i = lane; i < KP * KP; i += WAVE) {
         const int x = i / KP, y = i % KP;
@@ -1049,6 +1071,34 @@ __global__ void __launch_bounds__(64) k_level_reduce(LevelReduceArgs a)
         }
         eq[KP * KP + lane] = y;
     }
+}
+
+// Masked update of one continuous column (optimize_continuous_v2, src/optimize.cpp:102-126) on its reduced
+// normal equations eq = {H (KP x KP, no ridge term), b (KP)}: cyclic scalar coordinate descent
+// u_i = (b_i - sum_{l != i} H_il u_l) / (H_ii + lambda) until sum |u - u_previous_pass| < 0.1.  One wave.
+template <int NB>
+__global__ void __launch_bounds__(64) k_cont_cd(const double *__restrict__ eq, int K, double lambda,
+                                                double *__restrict__ urow /*KP*/)
+{
+    constexpr int KP = Geo<NB>::KP;
+    __shared__ double s_A[KP * KP];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < KP * KP; i += WAVE) s_A[i] = eq[i];
+    wave_sync();
+    const bool valid = lane < K;
+    const double b = valid ? eq[KP * KP + lane] : 0.0;
+    double u = valid ? urow[lane] : 0.0;
+    for (int pass = 0; pass < 100000; ++pass) {                                         // :102 while(1)
+        const double pre = u;
+        for (int i = 0; i < K; ++i) {                                                   // :104
+            const double dot = wave_sum(valid && lane != i ? s_A[i * KP + lane] * u : 0.0);
+            const double bi = readlane_d(b, i), hii = s_A[i * KP + i];
+            const double ui = (bi - dot) / (hii + lambda);                              // :117
+            if (lane == i) u = ui;
+        }
+        if (wave_sum(valid ? fabs(pre - u) : 0.0) < 1e-1) break;                        // :122
+    }
+    if (valid) urow[lane] = u;
 }
 
 // Stage 3 (one wave per level, after the cross-rank sum): add the ridge term and solve; write A_i[l].

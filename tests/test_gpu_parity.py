@@ -260,9 +260,10 @@ def test_bad_arguments_return_status():
     with pytest.raises(_lib.InsiderError) as e:
         ds.optimize(*_cp(w), w.K, tuning=5)
     assert e.value.status == _lib.ERR_ARG
-    with pytest.raises(_lib.InsiderError) as e:
-        ds.optimize(*_cp(w), w.K, inc_continuous=1)
-    assert e.value.status == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.InsiderError) as e:     # continuous factor asked for, but the handle has no ctns_confounder
+        A, C = _cp(w)
+        ds.optimize(A + [np.zeros((1, w.K), order="F")], C, w.K, inc_continuous=1)
+    assert e.value.status == _lib.ERR_ARG
     ds.close()
 
 
@@ -347,3 +348,39 @@ def test_allreduce_callback_plumbing_single_gpu(oracle):
         assert ar.calls == [6] + (per_iter * 1 + [6]) + per_iter * 9 + per_iter + [6]
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw,m", [(dict(), 1), (dict(with_na=True), 2), (dict(tuning=0), 2), (dict(K=17, n=90, p=70), 3)])
+def test_optimize_with_continuous_covariates(oracle, kw, m):
+    # optimize_continuous_v2 (src/optimize.cpp:76-137) through the weighted level machinery
+    w = workloads.small(**kw)
+    rng = np.random.default_rng(8)
+    Z = np.asfortranarray(rng.standard_normal((w.n, m)))
+    U0 = np.asfortranarray(rng.normal(0.0, 0.001, size=(m, w.K)))
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
+    A, C = _cp(w)
+    got = ds.optimize(A + [U0.copy(order="F")], C, w.K, w.lam, w.lam, w.alpha, tuning=w.tuning, max_iter=20, seed=5,
+                      inc_continuous=1)
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + [U0], w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          tuning=w.tuning, max_iter=20, seed=5, ctns=Z)
+    assert got["iters"] == ref["iters"]
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-8, equal_nan=True)
+    for i, a in enumerate(ref["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-6, i
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-6
+
+
+def test_operator_level_optimize_with_ctns(oracle):
+    # the reference's 16-argument optimize() with inc_continuous = 1 (R/RcppExports.R:20-22)
+    w = workloads.small(n=50, p=60)
+    rng = np.random.default_rng(2)
+    Z = np.asfortranarray(rng.standard_normal((w.n, 2)))
+    U0 = np.asfortranarray(rng.normal(0.0, 0.001, size=(2, w.K)))
+    A, C = _cp(w)
+    out = api.optimize(w.X, A + [U0.copy(order="F")], C, w.levels, Z, w.M_train, w.M_test, 1, w.K, w.lam, w.lam, w.alpha, 1,
+                       1e-10, 1e-5, 5, seed=3)
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + [U0], w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          max_iter=5, seed=3, ctns=Z)
+    assert relerr(out["column_factor"], ref["column_factor"]) < 1e-7
+    assert relerr(out["row_matrices"]["factor2"], ref["row_matrices"][2]) < 1e-7
