@@ -167,7 +167,7 @@ __device__ __forceinline__ void stream_line(const double *__restrict__ vals, con
 constexpr int SYRK_GB = 4;
 constexpr int SYRK_BATCH = 4 * SYRK_GB;        // list entries per batch
 constexpr int LIST_ALIGN = 2 * SYRK_BATCH;     // lists are padded to a multiple of two batches (ping-pong drain)
-constexpr int LIST_BLOCK = 64;                 // list entries staged through LDS at a time (one per lane)
+constexpr int LIST_BLOCK = 64;                 // list entries staged through LDS at a time (LIST_BLOCK / 64 per lane)
 constexpr int LIST_PAD = 0x7FFFFF;             // padding index: index * row bytes is beyond any factor buffer
 
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -507,19 +507,31 @@ k_list_stats(const uint32_t *__restrict__ ptr, const int *__restrict__ lidx, con
         const uint32_t first = e_begin + (uint32_t)b0 * LIST_ALIGN, last = e_begin + (uint32_t)b1 * LIST_ALIGN;
         const int nblk = __builtin_amdgcn_readfirstlane((int)((last - first + LIST_BLOCK - 1) / LIST_BLOCK));
         const int nbt = __builtin_amdgcn_readfirstlane((int)((last - first) / SYRK_BATCH));   // even
-        // two list blocks in flight in registers; entries beyond the segment are read as padding
-        auto ld_idx = [&](int blk) { const uint32_t e = first + (uint32_t)blk * LIST_BLOCK + lane; return e < last ? lidx[e] : LIST_PAD; };
-        auto ld_val = [&](int blk) { const uint32_t e = first + (uint32_t)blk * LIST_BLOCK + lane; return e < last ? lval[e] : 0.0; };
-        int i0 = ld_idx(0), i1 = ld_idx(1);
-        double x0 = ld_val(0), x1 = ld_val(1);
+        // two list blocks in flight in registers (EPL entries per lane each); entries beyond the segment read as padding
+        constexpr int EPL = LIST_BLOCK / WAVE;
+        int ia[EPL], ib[EPL];
+        double xa[EPL], xb[EPL];
+        auto ld = [&](int blk, int (&ii)[EPL], double (&xx)[EPL]) {
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                const uint32_t e = first + (uint32_t)blk * LIST_BLOCK + (uint32_t)(t * WAVE + lane);
+                const uint32_t ec = e < last ? e : last - 1;   // clamped address, value masked: loads stay unconditional
+                const int iv = lidx[ec];
+                const double xv = lval[ec];
+                ii[t] = e < last ? iv : LIST_PAD;
+                xx[t] = e < last ? xv : 0.0;
+            }
+        };
+        ld(0, ia, xa);
+        ld(1, ib, xb);
         for (int blk = 0; blk < nblk; ++blk) {
             int *li = s_li[w][blk & 1];
             double *lx = s_lx[w][blk & 1];
-            li[lane] = i0;
-            lx[lane] = x0;
-            i0 = i1; x0 = x1;
-            i1 = ld_idx(blk + 2);
-            x1 = ld_val(blk + 2);
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) { li[t * WAVE + lane] = ia[t]; lx[t * WAVE + lane] = xa[t]; }
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) { ia[t] = ib[t]; xa[t] = xb[t]; }
+            ld(blk + 2, ib, xb);
             wave_sync();
             const int left = nbt - blk * (LIST_BLOCK / SYRK_BATCH);
             drain_syrk<NB>(li, lx, left < LIST_BLOCK / SYRK_BATCH ? left : LIST_BLOCK / SYRK_BATCH, rsrc, acc, lane);

@@ -384,3 +384,40 @@ def test_operator_level_optimize_with_ctns(oracle):
                           max_iter=5, seed=3, ctns=Z)
     assert relerr(out["column_factor"], ref["column_factor"]) < 1e-7
     assert relerr(out["row_matrices"]["factor2"], ref["row_matrices"][2]) < 1e-7
+
+
+def test_caller_level_insider_tune_fit(oracle, tmp_path):
+    """The R-level workflow mirrored in insider_amd/api.py (R/insider.R:18-216): insider() -> tune() grid -> fit(),
+    against the oracle driven with the same masks and the same fresh inits per grid point."""
+    rng = np.random.default_rng(4)
+    conf = workloads.cyclic_levels(60, (5, 3))
+    A = [rng.standard_normal((5, 4)), rng.standard_normal((3, 4))]
+    Cs = rng.standard_normal((4, 80))
+    data = sum(A[i][conf[:, i] - 1] for i in range(2)) @ Cs + 0.5 * rng.standard_normal((60, 80))
+    data[rng.random(data.shape) < 0.03] = np.nan
+    obj = api.insider(data, conf, split_ratio=0.15, tuning_iter=12, max_iter=25, seed=99)
+    assert not (obj["train_indicator"] & obj["test_indicator"]).any()
+    lam, alp = [1.0, 3.0], [0.2, 0.5]
+    out = api.tune(obj, latent_dimension=np.array([4]), lambda_=lam, alpha=alp, out_dir=str(tmp_path),
+                   rng=np.random.default_rng(7))
+    assert out["latent_rank"] == 4 and out["reg_tuning"].shape == (4, 4)
+    assert (tmp_path / "insider_R4_reg_tuning_result.csv").exists()           # R/insider.R:172
+    # expand.grid(lambda, alpha): lambda varies fastest (R/insider.R:145)
+    assert [tuple(r[:2]) for r in out["reg_tuning"]] == [(1.0, 0.2), (3.0, 0.2), (1.0, 0.5), (3.0, 0.5)]
+    ref_rng = np.random.default_rng(7)
+    n_levels = np.array([5, 3], dtype=np.int32)
+    for row in out["reg_tuning"]:
+        cfd, col = api._fresh_inits(obj, 4, ref_rng)                            # same draws as tune() made
+        ref = oracle.optimize(obj["data"], obj["confounder"], n_levels, cfd, col, obj["train_indicator"],
+                              obj["test_indicator"], row[0], row[0], row[1], tuning=1, global_tol=1e-9, sub_tol=1e-5,
+                              max_iter=12, seed=99)
+        assert row[2] == pytest.approx(ref["train_rmse"], rel=1e-8) and row[3] == pytest.approx(ref["test_rmse"], rel=1e-8)
+    # fit(): indicator = train + test, "test" = NA mask, tuning = partition (R/insider.R:207-209)
+    obj = api.fit(obj, latent_dimension=4, lambda_=3.0, alpha=0.2, partition=1, rng=np.random.default_rng(11))
+    cfd, col = api._fresh_inits(obj, 4, np.random.default_rng(11))
+    ref = oracle.optimize(obj["data"], obj["confounder"], n_levels, cfd, col,
+                          obj["train_indicator"] + obj["test_indicator"], obj["na_indicator"], 3.0, 3.0, 0.2, tuning=1,
+                          global_tol=1e-9, sub_tol=1e-5, max_iter=25, seed=99)
+    assert relerr(obj["column_factor"], ref["column_factor"]) < 1e-6
+    assert obj["test_rmse"] == pytest.approx(ref["test_rmse"], rel=1e-7)
+    assert set(obj["cfd_matrices"]) == {"factor0", "factor1"}
