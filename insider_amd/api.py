@@ -301,8 +301,26 @@ def _fresh_inits(obj, latent_rank, rng):
     return cfd, col
 
 
-def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None):
-    """tune() of R/insider.R:81-176.  ``out_dir``: where to write the reference's CSVs (None = do not write)."""
+def _grid_sum(rows, world):
+    """Combine the per-rank result tables of a grid-parallel tune(): every rank filled only its own rows."""
+    if world <= 1:
+        return rows
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(rows))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None, rank=0, world=1):
+    """tune() of R/insider.R:81-176.  ``out_dir``: where to write the reference's CSVs (None = do not write).
+
+    ``rank`` / ``world``: grid-parallel tuning across the GPUs of a node: every rank keeps the
+    whole data set resident, grid point g is fitted by rank g % world and the result tables are summed over
+    torch.distributed.  The fresh inits of ALL grid points are drawn on every rank, in the reference's order, so
+    the tables do not depend on ``world``."""
     lat = np.atleast_1d(latent_dimension) if latent_dimension is not None else np.array([])
     lam = np.atleast_1d(np.asarray(lambda_, dtype=float))
     alp = np.atleast_1d(np.asarray(alpha, dtype=float))
@@ -317,10 +335,12 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
     ds = _resident(obj, "tune")
     rank_tuning, reg_tuning = None, None
     if lat.size > 1:                                                                                     # :98-132
-        rows = []
-        for latent_rank in lat:
-            print(f"Latent rank:  {int(latent_rank)} ---------------------------------")
+        rows = np.zeros((lat.size, 3))
+        for g, latent_rank in enumerate(lat):
             cfd, col = _fresh_inits(obj, int(latent_rank), rng)
+            if g % world != rank:
+                continue
+            print(f"Latent rank:  {int(latent_rank)} ---------------------------------")
             if lam.size == 1 and alp.size == 1:
                 l_, a_ = float(lam[0]), float(alp[0])
             else:
@@ -328,28 +348,33 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
             fitted = ds.optimize(cfd, col, int(latent_rank), l_, l_, a_, 1, prm["global_tol"], prm["sub_tol"],
                                  prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
                                  inc_continuous=obj["inc_continuous"])
-            rows.append((int(latent_rank), fitted["train_rmse"], fitted["test_rmse"]))
-            rank_tuning = np.array(rows)
-            if out_dir is not None:
-                np.savetxt(os.path.join(out_dir, "insider_rank_tuning_result.csv"), rank_tuning, delimiter=",")
+            rows[g] = (int(latent_rank), fitted["train_rmse"], fitted["test_rmse"])
+            if out_dir is not None and world == 1:
+                np.savetxt(os.path.join(out_dir, "insider_rank_tuning_result.csv"), rows[: g + 1], delimiter=",")
+        rank_tuning = _grid_sum(rows, world)
+        if out_dir is not None and world > 1 and rank == 0:
+            np.savetxt(os.path.join(out_dir, "insider_rank_tuning_result.csv"), rank_tuning, delimiter=",")
         latent_rank = int(lat[int(np.argmin(rank_tuning[:, 2]))])                                        # :136
     else:
         latent_rank = int(lat[0])
     if lam.size > 1 or alp.size > 1:                                                                     # :142-174
-        rows = []
-        for a_ in alp:                      # expand.grid(lambda, alpha): lambda varies fastest
-            for l_ in lam:
-                l_r, a_r = round(float(l_), 2), round(float(a_), 2)                                      # :149-150
-                print(f"parameter grid: {l_r},{a_r} ---------------------------------")
-                cfd, col = _fresh_inits(obj, latent_rank, rng)
-                fitted = ds.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
-                                     prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
-                                     inc_continuous=obj["inc_continuous"])
-                rows.append((l_r, a_r, fitted["train_rmse"], fitted["test_rmse"]))
-                reg_tuning = np.array(rows)
-                if out_dir is not None:
-                    np.savetxt(os.path.join(out_dir, f"insider_R{latent_rank}_reg_tuning_result.csv"), reg_tuning,
-                               delimiter=",")
+        grid = [(round(float(l_), 2), round(float(a_), 2)) for a_ in alp for l_ in lam]   # expand.grid: lambda fastest
+        rows = np.zeros((len(grid), 4))
+        csv = os.path.join(out_dir, f"insider_R{latent_rank}_reg_tuning_result.csv") if out_dir is not None else None
+        for g, (l_r, a_r) in enumerate(grid):                                                            # :147-150
+            cfd, col = _fresh_inits(obj, latent_rank, rng)
+            if g % world != rank:
+                continue
+            print(f"parameter grid: {l_r},{a_r} ---------------------------------")
+            fitted = ds.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
+                                 prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
+                                 inc_continuous=obj["inc_continuous"])
+            rows[g] = (l_r, a_r, fitted["train_rmse"], fitted["test_rmse"])
+            if csv and world == 1:
+                np.savetxt(csv, rows[: g + 1], delimiter=",")
+        reg_tuning = _grid_sum(rows, world)
+        if csv and world > 1 and rank == 0:
+            np.savetxt(csv, reg_tuning, delimiter=",")
     return dict(rank_tuning=rank_tuning, latent_rank=latent_rank, reg_tuning=reg_tuning)
 
 

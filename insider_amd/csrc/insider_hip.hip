@@ -112,7 +112,7 @@ struct insider_hip_handle {
     insider_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
     // options
-    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0, dbg_skip_drain = 0, cd_variant = 0, force_allreduce = 0;
+    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0, cd_variant = 0, force_allreduce = 0;
     // profile of the last optimize()
     std::vector<hipEvent_t> ev_col, ev_row, ev_cd, ev_test;
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -832,7 +832,6 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "order_mode") h->order_mode = (int)value;
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
-    else if (s == "dbg_skip_drain") h->dbg_skip_drain = (int)value;
     else if (s == "force_allreduce") h->force_allreduce = (int)value;   // call the all-reduce callback even when world == 1
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = row16 (4 genes per wave, K <= 32), 1 = group kernel
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);

@@ -122,3 +122,55 @@ def test_two_rank_row_update_and_loss_match_unsharded(oracle):
     np.testing.assert_allclose(outs[0][2], exp, rtol=1e-10)
     # exchange volume: one all-reduce per covariate of L_i (K^2 + K) doubles, one of 6 for the loss
     assert outs[0][3] == [5 * (16 + 4), 4 * (16 + 4), 6]
+
+
+# ---- grid-parallel tune(): the host logic, with the device fit stubbed out ----------------------
+class _FakeData:
+    """Stands in for the HBM-resident data set: a deterministic function of the inits and hyper-parameters."""
+
+    def optimize(self, cfd, col, K, l1, l2, a, tuning, gtol, stol, iters, seed=0, inc_continuous=0):
+        s = float(sum(np.sum(m) for m in cfd) + np.sum(col))
+        return dict(train_rmse=1e3 * s + l1, test_rmse=1e3 * s + 10 * a + K)
+
+
+def _tune_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from insider_amd import api
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        obj = api.Insider(params=dict(global_tol=1e-9, sub_tol=1e-5, tuning_iter=3, max_iter=5), inc_continuous=0,
+                          confounder=workloads.cyclic_levels(12, (3, 2)), data=np.zeros((12, 9)), seed=1)
+        obj["_resident_tune"] = _FakeData()
+        out = api.tune(obj, latent_dimension=np.array([2, 3, 4]), lambda_=[1.0, 2.0, 3.0], alpha=[0.1, 0.2],
+                       rng=np.random.default_rng(5), rank=rank, world=world)
+        q.put((rank, out["rank_tuning"], out["latent_rank"], out["reg_tuning"]))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_grid_parallel_tune_matches_serial():
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_tune_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[world] = outs
+    serial = results[1][0]
+    for r in results[2]:   # every rank of the 2-rank job ends with the serial tables
+        np.testing.assert_allclose(r[1], serial[1], rtol=1e-13)
+        assert r[2] == serial[2]
+        np.testing.assert_allclose(r[3], serial[3], rtol=1e-13)
+    assert serial[3].shape == (6, 4) and serial[1].shape == (3, 3)
