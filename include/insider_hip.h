@@ -48,10 +48,13 @@ extern "C" {
 typedef struct insider_hip_handle insider_hip_handle;
 
 /* Sum-all-reduce of `count` doubles at device pointer `dev_buf`, in place, across the gene-sharded ranks.
- * Called by insider_hip_optimize() on the calling thread after the producing kernels have completed
- * (the stream is synchronised before the call); must return 0 on success after the reduced values are
- * visible in dev_buf to subsequent work on any stream. */
-typedef int (*insider_allreduce_fn)(void *user, double *dev_buf, int64_t count);
+ * Called by insider_hip_optimize() on the calling thread.  `stream` is the library's HIP stream (a hipStream_t):
+ * the kernels producing dev_buf have been ENQUEUED on it, not necessarily completed, and the consumers will be
+ * enqueued on it after the call returns.  The callback must therefore order the reduction after the prior work of
+ * `stream` and before its later work — either by enqueueing the collective on / against that stream (no host
+ * synchronisation needed; insider_amd/dist.py does this through torch.cuda.ExternalStream), or by synchronising
+ * the stream, reducing, and synchronising again.  Return 0 on success. */
+typedef int (*insider_allreduce_fn)(void *user, double *dev_buf, int64_t count, void *stream);
 
 const char *insider_hip_version(void);
 const char *insider_hip_last_error(void);

@@ -15,7 +15,7 @@ OK, ERR_ARG, ERR_SOLVE, ERR_ALLOC, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_
 TRAJ_STRIDE = 10
 MAX_K = 63
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 # every symbol include/insider_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (

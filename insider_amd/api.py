@@ -58,13 +58,14 @@ class InsiderData:
         _lib.check(_lib.load().insider_hip_set_option(self._h, name.encode(), float(value)))
 
     def set_shard(self, gene_offset, rank, world, allreduce=None):
-        """allreduce(ptr:int, count:int) -> None sums `count` doubles at device pointer `ptr` across ranks in place."""
+        """allreduce(ptr:int, count:int, stream:int) -> None sums `count` doubles at device pointer `ptr` across ranks in
+        place, ordered against the library's HIP stream `stream` (see include/insider_hip.h)."""
         if allreduce is None:
             cb = C.cast(None, _lib.ALLREDUCE_FN)
         else:
-            def _tramp(_user, ptr, count):
+            def _tramp(_user, ptr, count, stream):
                 try:
-                    allreduce(int(ptr), int(count))
+                    allreduce(int(ptr), int(count), int(stream or 0))
                     return 0
                 except Exception as e:  # never unwind through the C frame
                     print(f"[insider_amd] all-reduce callback failed: {e!r}", flush=True)

@@ -428,8 +428,9 @@ int launch_row_stats(insider_hip_handle *h, bool timed)
 int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
 {
     if ((h->world <= 1 && !h->force_allreduce) || !h->allreduce) return INSIDER_OK;
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    if (h->allreduce(h->allreduce_user, buf, count) != 0) return fail(INSIDER_ERR_COMM, "all-reduce callback failed");
+    // stream-ordered: the callback enqueues the collective against h->stream (see include/insider_hip.h)
+    if (h->allreduce(h->allreduce_user, buf, count, (void *)h->stream) != 0)
+        return fail(INSIDER_ERR_COMM, "all-reduce callback failed");
     return INSIDER_OK;
 }
 

@@ -29,7 +29,7 @@ class HostAllreduce:
         self.group = group
         self.calls = []
 
-    def __call__(self, ptr, count):
+    def __call__(self, ptr, count, stream=0):
         import torch
         arr = np.ctypeslib.as_array((C.c_double * count).from_address(ptr))
         t = torch.from_numpy(arr)
@@ -44,10 +44,13 @@ class _DevBuf:
 
 
 class DeviceAllreduce:
-    """All-reduce of a DEVICE buffer given by address, through torch.distributed (RCCL).
+    """All-reduce of a DEVICE buffer given by address, through torch.distributed (RCCL), ordered against the HIP stream
+    the library passes in: the stream is wrapped in a torch.cuda.ExternalStream and made current for the call, so
+    ProcessGroupNCCL makes its collective wait for the stream's prior kernels and the stream wait for the collective.
+    No host synchronisation: the host keeps enqueueing the next kernels while the GPU works.
 
-    Zero-copy when torch accepts the pointer through __cuda_array_interface__ (checked once by writing through the
-    alias); otherwise staged through a torch-owned buffer with device-to-device copies.
+    Zero-copy when torch accepts the pointer through __cuda_array_interface__ (checked once); otherwise staged through
+    a torch-owned buffer with synchronous device-to-device copies.
     """
 
     def __init__(self, device, group=None):
@@ -58,6 +61,7 @@ class DeviceAllreduce:
         self.zero_copy = None
         self.stage = None
         self.hip = None
+        self.ext = {}
         self.calls = []
 
     def _alias(self, ptr, count):
@@ -74,16 +78,27 @@ class DeviceAllreduce:
         if not ok:
             self.hip = C.CDLL("libamdhip64.so")
             self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
 
-    def __call__(self, ptr, count):
+    def _stream(self, stream):
+        if stream not in self.ext:
+            self.ext[stream] = self.torch.cuda.ExternalStream(stream, device=self.device)
+        return self.ext[stream]
+
+    def __call__(self, ptr, count, stream=0):
         torch = self.torch
         if self.zero_copy is None:
             self._probe(ptr, count)
-        if self.zero_copy:
-            t = self._alias(ptr, count)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.zero_copy and stream:
+            with torch.cuda.stream(self._stream(stream)):
+                self.dist.all_reduce(self._alias(ptr, count), op=self.dist.ReduceOp.SUM, group=self.group)
+        elif self.zero_copy:
+            torch.cuda.synchronize(self.device)
+            self.dist.all_reduce(self._alias(ptr, count), op=self.dist.ReduceOp.SUM, group=self.group)
             torch.cuda.synchronize(self.device)
         else:
+            if stream:
+                self.hip.hipStreamSynchronize(stream)
             if self.stage is None or self.stage.numel() < count:
                 self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device=self.device)
             if self.hip.hipMemcpy(self.stage.data_ptr(), ptr, count * 8, 3) != 0:

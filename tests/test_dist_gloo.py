@@ -67,7 +67,7 @@ def _worker(rank, world, port, q):
         new_A = [a.copy() for a in A]
         for cov in range(w.levels.shape[1]):          # Gauss-Seidel over covariates: one all-reduce each
             eq = np.ascontiguousarray(_slab_level_equations(w, new_A, Cm, cov, lo, hi))
-            ar(eq.ctypes.data, eq.size)               # the callback signature the C ABI uses: (pointer, count)
+            ar(eq.ctypes.data, eq.size, 0)            # the callback signature the C ABI uses: (pointer, count, stream)
             for l in range(eq.shape[0]):
                 XtX = eq[l, :K * K].reshape(K, K) + lam * np.eye(K)
                 new_A[cov][l] = np.linalg.solve(XtX, eq[l, K * K:])
@@ -77,7 +77,7 @@ def _worker(rank, world, port, q):
         tr, te = w.M_train[:, lo:hi] != 0, w.M_test[:, lo:hi] != 0
         buf = np.array([np.sum(resid[tr] ** 2), np.sum(resid[te] ** 2), np.sum(Cm[:, lo:hi] ** 2),
                         np.sum(np.abs(Cm[:, lo:hi])), tr.sum(), te.sum()], dtype=np.float64)
-        ar(buf.ctypes.data, buf.size)
+        ar(buf.ctypes.data, buf.size, 0)
         q.put((rank, [a.copy() for a in new_A], buf.copy(), list(ar.calls)))
     finally:
         dist.destroy_process_group()

@@ -346,6 +346,8 @@ def test_allreduce_callback_plumbing_single_gpu(oracle):
         per_iter = [int(L) * (KP * KP + KP) for L in w.n_levels]
         # 11 outer iterations x one all-reduce per covariate, + 6 doubles per loss evaluation (initial + iter 0, 10)
         assert ar.calls == [6] + (per_iter * 1 + [6]) + per_iter * 9 + per_iter + [6]
+        assert ar.zero_copy in (True, False)
+        print("all-reduce zero-copy aliasing:", ar.zero_copy)
     finally:
         dist.destroy_process_group()
 
