@@ -305,7 +305,10 @@ __global__ void __launch_bounds__(64) k_cd_cols_r16(ColArgs a)
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u)
             if (gene && 16 * u + i < K) a.C[(size_t)j * KP + 16 * u + i] = beta[u];
-        if (gene && i == 0) a.sweeps[j] = sweeps;
+        if (gene && i == 0) {
+            a.sweeps[j] = sweeps;
+            if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
+        }
     }
     if (!a.checkpoint) return;
     // ---- loss statistics with the (updated) column, coordinate order: fresh g = q - XtX beta -------------------------

@@ -184,7 +184,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->stage, h->stage_count))) return rc;
     if ((rc = dmalloc(&h->sweeps, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->failflag, 1))) return rc;
-    if ((rc = dmalloc(&h->sweep_total, 1))) return rc;
+    if ((rc = dmalloc(&h->sweep_total, 256))) return rc;
     if ((rc = dmalloc(&h->gene_ids, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sweeps_sorted, (size_t)h->p))) return rc;
@@ -370,6 +370,7 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.sse_test = h->sse_test;
         a.test_from_stats = masked && h->no_na;
         a.sweeps = h->sweeps;
+        a.sweep_bins = (timed && solve) ? h->sweep_total : nullptr;
         a.gene_perm = (solve && h->have_perm) ? h->gene_perm : nullptr;
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
         if (h->cd_variant == 0 && h->K <= 16)
@@ -388,11 +389,6 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweeps, h->sweeps_sorted,
                                                               h->gene_ids, h->gene_perm, (int)h->p, 0, 32, h->stream));
         h->have_perm = true;
-    }
-    if (timed && solve && h->profile) {
-        hipLaunchKernelGGL(k_accum_sweeps, dim3(1), dim3(256), 0, h->stream, (const int *)h->sweeps, (int)h->p,
-                           h->sweep_total);
-        KCHECK();
     }
     return INSIDER_OK;
 }
@@ -904,7 +900,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
 
     uint32_t iter = 0;
     unsigned long long sweeps_total = 0;
-    HIPCHECK(hipMemsetAsync(h->sweep_total, 0, sizeof(unsigned long long), h->stream));
+    HIPCHECK(hipMemsetAsync(h->sweep_total, 0, 256 * sizeof(unsigned long long), h->stream));
     while (iter <= max_iter) {                                                                  // :325
         if (h->verbose && iter % 10 == 0) printf("Iteration %u ---------------------------------\n", iter);
         // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
@@ -983,7 +979,11 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     HIPCHECK(hipMemcpyAsync(C, h->stage, (size_t)h->p * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     if ((rc = check_fail_flag(h))) return rc;
-    HIPCHECK(hipMemcpy(&sweeps_total, h->sweep_total, sizeof(sweeps_total), hipMemcpyDeviceToHost));
+    {
+        unsigned long long bins[256];
+        HIPCHECK(hipMemcpy(bins, h->sweep_total, sizeof(bins), hipMemcpyDeviceToHost));
+        for (unsigned long long v : bins) sweeps_total += v;
+    }
     if (out_train_rmse) *out_train_rmse = train_rmse;
     if (out_test_rmse) *out_test_rmse = test_rmse;
     if (out_loss) *out_loss = loss;

@@ -447,6 +447,7 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
 __device__ __forceinline__ bool chol_solve_lds(double *A, int KP, int K, double &b, int lane)
 {
     const bool valid = lane < K;
+    const int lm = lane >> 3, ll = lane & 7;   // 8 x 8 tile of the trailing matrix per step
     for (int j = 0; j < K; ++j) {
         const double d = A[j * KP + j];
         if (!(d > 0.0)) return false;
@@ -458,9 +459,14 @@ __device__ __forceinline__ bool chol_solve_lds(double *A, int KP, int K, double 
         if (lane == j) A[j * KP + j] = s;
         if (below) { A[j * KP + lane] = lij; A[lane * KP + j] = lij; }
         wave_sync();
-        for (int m = j + 1; m < K; ++m) {
-            const double lmj = A[j * KP + m];
-            if (below) A[m * KP + lane] -= lmj * lij;
+        // trailing update A[m][l] -= L[m][j] L[l][j] for j < m, l < K, all 64 lanes busy (row j now holds L[.][j])
+        for (int m0 = j + 1; m0 < K; m0 += 8) {
+            const int m = m0 + lm;
+            const double lmj = m < K ? A[j * KP + m] : 0.0;
+            for (int l0 = j + 1; l0 < K; l0 += 8) {
+                const int l = l0 + ll;
+                if (m < K && l < K) A[m * KP + l] -= lmj * A[j * KP + l];
+            }
         }
         wave_sync();
     }
@@ -613,6 +619,7 @@ struct ColArgs {
     double *sse_test;        // p; written when test_from_stats
     int test_from_stats;     // no NA entry in the data: held-out == test, so the test residuals follow from the statistics
     int *sweeps;             // p
+    unsigned long long *sweep_bins;   // 256 counters: total sweeps of the launch, spread to keep the atomics cheap
     const int *gene_perm;    // launch slot -> gene (genes sorted by their last sweep count, longest first), or null
 };
 
@@ -653,7 +660,10 @@ __global__ void __launch_bounds__(WPB * 64) k_cd_cols(ColArgs a)
     if (a.mode == COL_CD) {                                                             // :228,246
         sweeps = cd_sweeps<W>(Goff, s_ord[w], K, Gll, q, beta, g, valid, a.cd, lane);
         if (valid) a.C[(size_t)j * KP + l] = beta;
-        if (gene && l == 0) a.sweeps[j] = sweeps;
+        if (gene && l == 0) {
+            a.sweeps[j] = sweeps;
+            if (a.sweep_bins) atomicAdd(&a.sweep_bins[(blockIdx.x * WPB + w) & 255], (unsigned long long)sweeps);
+        }
     }
     if (!a.checkpoint) return;
     // ---- loss statistics with the (updated) column: sum_train (x - r'b)^2 = yy - 2 b'q + b'XtX b = yy - b'(q + g)
@@ -986,7 +996,24 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) hsum[b] = d4{0.0, 0.0, 0.0, 0.0};
     double v = 0.0, ssum = 0.0, w2sum = 0.0;
-    for (int mi = a.chunk_begin[ch]; mi < a.chunk_end[ch]; ++mi) {
+    // the statistics of member mi + 1 are loaded while member mi is processed
+    auto load_stat = [&](int mi, d4 (&h)[NBLK]) {
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) h[b] = d4{0.0, 0.0, 0.0, 0.0};
+        if (!a.masked) return;
+        const int r = a.members[mi];
+        for (int sg = 0; sg < a.nseg; ++sg) {
+            const double *src = a.stat + ((size_t)sg * a.n + r) * STAT;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[b][q] += src[b * 256 + (sub + 4 * q) * 16 + c16];
+        }
+    };
+    const int m_begin = a.chunk_begin[ch], m_end = a.chunk_end[ch];
+    d4 hn[NBLK];
+    load_stat(m_begin, hn);
+    for (int mi = m_begin; mi < m_end; ++mi) {
         const int r = a.members[mi];
         const double w = a.weights ? a.weights[r] : 1.0;
         // s_r: everything but this covariate's own contribution (the Gauss-Seidel residual of :338,344 is x_r - s_r'C)
@@ -1000,14 +1027,8 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
         if (a.masked) {
             d4 h[NBLK];
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) h[b] = d4{0.0, 0.0, 0.0, 0.0};
-            for (int sg = 0; sg < a.nseg; ++sg) {
-                const double *src = a.stat + ((size_t)sg * a.n + r) * STAT;
-#pragma unroll
-                for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) h[b][q] += src[b * 256 + (sub + 4 * q) * 16 + c16];
-            }
+            for (int b = 0; b < NBLK; ++b) h[b] = hn[b];
+            load_stat(mi + 1 < m_end ? mi + 1 : mi, hn);
             wave_sync();
             acc_to_lds<NB>(h, s_H, lane);
             if (lane < KP) s_s[lane] = valid ? s : 0.0;
