@@ -89,6 +89,7 @@ struct insider_hip_handle {
     uint32_t *col_ptr = nullptr, *row_ptr = nullptr;
     int *col_idx = nullptr, *row_idx = nullptr;
     double *col_val = nullptr, *row_val = nullptr;
+    uint8_t *col_flag = nullptr;   // per column-side list entry: 1 = test entry (only kept when the data has NA entries)
     uint64_t col_entries = 0, row_entries = 0;
     // factor-dependent workspace for the current K
     int K = 0, NB = 0, KP = 0, nseg = 1, seg_len = 0;
@@ -404,9 +405,9 @@ int launch_test_sse(insider_hip_handle *h, int masked, bool timed)
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_test_sse<4>), dim3(cdiv(h->p, 4)), dim3(256), 0, h->stream, (const double *)h->X,
-                       (const uint8_t *)h->codes, h->ldn, (int)h->p, (const double *)h->R, (const double *)h->C, h->K,
-                       h->KP, h->sse_test);
+    hipLaunchKernelGGL((k_test_sse_list<4>), dim3(cdiv(h->p, 4)), dim3(256), 0, h->stream, (const uint32_t *)h->col_ptr,
+                       (const int *)h->col_idx, (const double *)h->col_val, (const uint8_t *)h->col_flag, (int)h->p,
+                       (const double *)h->R, (const double *)h->C, h->K, h->KP, h->sse_test);
     KCHECK();
     return t.end(h, h->ev_test);
 }
@@ -567,7 +568,7 @@ void insider_hip_destroy(insider_hip_handle *h)
     free_workspace(h);
     void *ptrs[] = {h->X, h->Xt, h->codes, h->codes_t, h->lev, h->lvl_off_d, h->members_all, h->lvl_ptr_all,
                     h->lvl_count_all, h->S, h->yy_train, h->yy_all, h->col_ptr, h->row_ptr, h->col_idx, h->row_idx,
-                    h->col_val, h->row_val, h->Zc, h->one_count, h->ident_members, h->cont.chunk_begin, h->cont.chunk_end,
+                    h->col_val, h->row_val, h->col_flag, h->Zc, h->one_count, h->ident_members, h->cont.chunk_begin, h->cont.chunk_end,
                     h->cont.lvl_chunk_ptr};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (auto &ct : h->cov) {
@@ -792,8 +793,10 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
         CR(dmalloc(&didx, (size_t)tot + LIST_BLOCK));
         CR(dmalloc(&dval, (size_t)tot + LIST_BLOCK));
         CH(hipMemcpyAsync(dptr, ptr.data(), ptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        uint8_t *dflag = nullptr;
+        if (cols && !h->no_na) { CR(dmalloc(&h->col_flag, (size_t)tot + LIST_BLOCK)); dflag = h->col_flag; }
         hipLaunchKernelGGL(k_fill_lists, dim3(cdiv(lines, 4)), dim3(256), 0, h->stream, vals, cds, pitch, len, lines,
-                           (const uint32_t *)dptr, didx, dval);
+                           (const uint32_t *)dptr, didx, dval, dflag);
         CH(hipGetLastError());
         CH(hipStreamSynchronize(h->stream));
     }

@@ -28,7 +28,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int WAVE = 64;
-constexpr int LIST_CAP = 512;   // held-out ring entries per wave (>= 2 * 128)
 constexpr int CHUNK = 128;      // elements per streaming step (2 per lane); line pitches are multiples of it
 
 constexpr int ORDER_ROW = 128;   // bytes per sweep in the coordinate-order table (see k_order_table)
@@ -78,77 +77,6 @@ __device__ __forceinline__ double wave_max(double v)
 }
 
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
-
-// ---------------------------------------------------------------------------------------------
-// streaming + compaction of one line
-// ---------------------------------------------------------------------------------------------
-// Streams `pitch` (multiple of CHUNK) elements of one line, appends those whose code passes the filter to the
-// wave's LDS ring (element index * TAG_MUL, value) in ascending element order and calls drain(ngroups) whenever
-// the ring could overflow, and once at the end after padding to a multiple of GROUP with (-1, 0.0) dummies.
-//   FILTER 0: held out of the train set (code & CODE_TRAIN) == 0      FILTER 1: test entries (code & CODE_TEST)
-template <int FILTER, int GROUP, int TAG_MUL, class Drain>
-__device__ __forceinline__ void stream_line(const double *__restrict__ vals, const uint8_t *__restrict__ codes,
-                                            int pitch, int *li, double *lx, int lane, Drain &&drain)
-{
-    constexpr int D = 4;   // chunks in flight per wave: the loads of chunk i + D are issued before chunk i is used
-    int cnt = 0;
-    const uint64_t lt = lanemask_lt(lane);
-    d2 xq[D];
-    uint32_t cq[D];   // 32-bit slots: 16-bit ones get packed two per VGPR, which forces a wait on every load
-    const int last = pitch - CHUNK;   // loads past the line are clamped to its last chunk (their data is never used)
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-        const int e0 = (u * CHUNK < last ? u * CHUNK : last) + 2 * lane;
-        xq[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vals + e0));
-        cq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(codes + e0));
-    }
-    for (int base0 = 0; base0 < pitch; base0 += D * CHUNK) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int base = base0 + u * CHUNK;
-            if (base >= pitch) break;
-            const int e0 = base + 2 * lane;
-            const d2 xv = xq[u];
-            const uint32_t cw = cq[u];
-            const int nb = (base + D * CHUNK < last ? base + D * CHUNK : last) + 2 * lane;
-            const int c0 = cw & 0xff, c1 = cw >> 8;
-            const bool h0 = FILTER == 0 ? !(c0 & CODE_TRAIN) : (c0 & CODE_TEST) != 0;
-            const bool h1 = FILTER == 0 ? !(c1 & CODE_TRAIN) : (c1 & CODE_TEST) != 0;
-            const uint64_t b0 = __ballot(h0), b1 = __ballot(h1);
-            const int n0 = __popcll(b0), n01 = n0 + __popcll(b1);
-            // vmcnt retires in order: a prefetch issued just before a drain would put a full HBM latency in front
-            // of the drain's first gather wait, so in that case it is issued after the drain
-            const bool will_drain = cnt + n01 > LIST_CAP - CHUNK;
-            if (!will_drain) {
-                xq[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vals + nb));
-                cq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(codes + nb));
-            }
-            if (n01) {
-                if (h0) { const int pos = cnt + __popcll(b0 & lt); li[pos] = e0 * TAG_MUL; lx[pos] = xv.x; }
-                if (h1) { const int pos = cnt + n0 + __popcll(b1 & lt); li[pos] = (e0 + 1) * TAG_MUL; lx[pos] = xv.y; }
-                cnt += n01;
-            }
-            if (will_drain) {
-                wave_sync();
-                const int ng = cnt / GROUP;
-                drain(ng);
-                const int rem = cnt - ng * GROUP;   // < GROUP <= 64
-                int ti = 0; double tx = 0.0;
-                if (lane < rem) { ti = li[ng * GROUP + lane]; tx = lx[ng * GROUP + lane]; }
-                wave_sync();
-                if (lane < rem) { li[lane] = ti; lx[lane] = tx; }
-                cnt = rem;
-                xq[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vals + nb));
-                cq[u] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(codes + nb));
-            }
-        }
-    }
-    const int padded = (cnt + GROUP - 1) / GROUP * GROUP;
-    for (int i = cnt + lane; i < padded; i += WAVE) { li[i] = -1; lx[i] = 0.0; }
-    wave_sync();
-    if (padded) drain(padded / GROUP);
-    wave_sync();
-}
 
 // ---------------------------------------------------------------------------------------------
 // SYRK on gathered rows over a line's precomputed held-out list
@@ -568,7 +496,8 @@ __global__ void __launch_bounds__(256) k_count_heldout(const uint8_t *__restrict
 // (element index, value) of every held-out entry of a line, ascending, padded to a multiple of LIST_ALIGN
 __global__ void __launch_bounds__(256) k_fill_lists(const double *__restrict__ vals, const uint8_t *__restrict__ codes,
                                                     int64_t pitch, int len, int lines, const uint32_t *__restrict__ ptr,
-                                                    int *__restrict__ lidx, double *__restrict__ lval)
+                                                    int *__restrict__ lidx, double *__restrict__ lval,
+                                                    uint8_t *__restrict__ lflag /*optional: 1 = test entry*/)
 {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + w;
@@ -577,16 +506,18 @@ __global__ void __launch_bounds__(256) k_fill_lists(const double *__restrict__ v
     const uint64_t lt = lanemask_lt(lane);
     for (int base = 0; base < len; base += WAVE) {
         const int i = base + lane;
-        const bool held = i < len && !(codes[(size_t)j * pitch + i] & CODE_TRAIN);
+        const int cd = i < len ? codes[(size_t)j * pitch + i] : CODE_TRAIN;
+        const bool held = !(cd & CODE_TRAIN);
         const uint64_t b = __ballot(held);
         if (held) {
             const uint32_t o = pos + (uint32_t)__popcll(b & lt);
             lidx[o] = i;
             lval[o] = vals[(size_t)j * pitch + i];
+            if (lflag) lflag[o] = (cd & CODE_TEST) ? 1 : 0;
         }
         pos += (uint32_t)__popcll(b);
     }
-    for (uint32_t o = pos + lane; o < ptr[j + 1]; o += WAVE) { lidx[o] = LIST_PAD; lval[o] = 0.0; }
+    for (uint32_t o = pos + lane; o < ptr[j + 1]; o += WAVE) { lidx[o] = LIST_PAD; lval[o] = 0.0; if (lflag) lflag[o] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -760,34 +691,31 @@ __global__ void __launch_bounds__(WPB * 64) k_ridge_cols(RidgeArgs a)
     }
 }
 
-// sum over the test entries of one line of (x - f_e' beta)^2 (evaluate(), src/utils.cpp:67), one wave per line
+// sum over the TEST entries of one gene of (x - r_i' beta)^2 (evaluate(), src/utils.cpp:67), from the gene's held-out
+// list with per-entry flags (data with NA entries: held-out = test + NA).  One wave per gene, one entry per lane,
+// beta broadcast from LDS.
 template <int WPB>
 __global__ void __launch_bounds__(WPB * 64)
-k_test_sse(const double *__restrict__ vals, const uint8_t *__restrict__ codes, int64_t pitch, int lines,
-           const double *__restrict__ F /*[len][KP]*/, const double *__restrict__ B /*[lines][KP]*/, int K, int KP,
-           double *__restrict__ sse_test)
+k_test_sse_list(const uint32_t *__restrict__ ptr, const int *__restrict__ lidx, const double *__restrict__ lval,
+                const uint8_t *__restrict__ lflag, int lines, const double *__restrict__ F /*rows of pitch KP*/,
+                const double *__restrict__ B /*[lines][KP]*/, int K, int KP, double *__restrict__ sse_test)
 {
-    __shared__ int s_li[WPB][LIST_CAP];
-    __shared__ double s_lx[WPB][LIST_CAP];
+    __shared__ double s_b[WPB][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * WPB + w;
     if (j >= lines) return;
-    int *li = s_li[w];
-    double *lx = s_lx[w];
-    const double beta = lane < K ? B[(size_t)j * KP + lane] : 0.0;
-    const int64_t off = (int64_t)j * pitch;
+    s_b[w][lane] = lane < K ? B[(size_t)j * KP + lane] : 0.0;
+    wave_sync();
     double te = 0.0;
-    stream_line<1, 64, 1>(vals + off, codes + off, (int)pitch, li, lx, lane, [&](int ng) {
-        for (int gi = 0; gi < ng; ++gi) {
-            const int e = li[64 * gi + lane];
-            const double xv = lx[64 * gi + lane];
-            const double *row = F + (size_t)(e < 0 ? 0 : e) * KP;
+    for (uint32_t e = ptr[j] + lane; e < ptr[j + 1]; e += WAVE) {
+        if (lflag[e]) {
+            const double *row = F + (size_t)lidx[e] * KP;
             double dot = 0.0;
-            for (int k = 0; k < K; ++k) dot += row[k] * readlane_d(beta, k);
-            const double r = xv - dot;
-            te += e < 0 ? 0.0 : r * r;
+            for (int k = 0; k < K; ++k) dot += row[k] * s_b[w][k];
+            const double r = lval[e] - dot;
+            te += r * r;
         }
-    });
+    }
     te = wave_sum(te);
     if (lane == 0) sse_test[j] = te;
 }
@@ -1295,21 +1223,6 @@ __global__ void __launch_bounds__(256) k_loss_reduce(const double *__restrict__ 
     }
     if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x][0];
     if (threadIdx.x == 4) out[6] = red[4][0];
-}
-
-// total += sum_j sweeps[j]   (profiling only)
-__global__ void __launch_bounds__(256) k_accum_sweeps(const int *__restrict__ sweeps, int p, unsigned long long *total)
-{
-    __shared__ unsigned long long red[256];
-    unsigned long long s = 0;
-    for (int j = threadIdx.x; j < p; j += 256) s += (unsigned long long)sweeps[j];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total += red[0];
 }
 
 // dense X'F over all elements of every line (stand-alone reductions only; optimize() gets it from level sums)
