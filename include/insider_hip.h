@@ -126,6 +126,27 @@ int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *
                                  uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss);
 
 /*
+ * The two block updates as stand-alone operators (the reference's internal optimize_row / optimize_col, reachable
+ * there only through optimize()).  Both take the factors in the host layout of insider_hip_optimize.
+ *
+ * insider_hip_optimize_row — one row update of covariate `cov` (src/optimize.cpp:139-198 as called at :339): the
+ *   residual is X minus the contributions of every other covariate as passed in A; A[cov] (L_cov x K) is replaced by
+ *   the per-level solutions of (sum_{r in level}(CC' - C_z C_z') + lambda I) a = sum_r C_nz resid[r, nz] (tuning = 1)
+ *   or (|level| CC' + lambda I) a = sum_r C resid[r, :]' (tuning = 0).  lambda >= 0: lambda = 0 with the other
+ *   factors zero is fit_interaction()'s arithmetic (src/fit_interaction.cpp:10-90, which applies no ridge term).
+ *   cov in [c, c+m) with inc_continuous = 1 updates row cov-c of the continuous factor (optimize_continuous_v2,
+ *   src/optimize.cpp:76-137).  Returns INSIDER_ERR_SOLVE when a level's system is not positive definite.
+ * insider_hip_optimize_col — one column update (src/optimize.cpp:200-253 as called at :376): every gene's
+ *   elastic-net regression of X[:, j] on the row factor R = sum_i Z_i A_i over its training entries, warm-started
+ *   at C[:, j] (alpha > 0), or the ridge solve (alpha == 0); C is updated in place.  `iter` picks the sweep-order
+ *   stream of include/insider_perm.h (optimize() passes its outer iteration number).
+ */
+int insider_hip_optimize_row(insider_hip_handle *h, double *const *A, const double *C, int inc_continuous, int K, int cov,
+                             double lambda, int tuning);
+int insider_hip_optimize_col(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K,
+                             double lambda, double alpha, int tuning, double tol, uint64_t seed, uint32_t iter);
+
+/*
  * strong_coordinate_descent (src/coordinate_descent.cpp:56-127; .Call symbol
  * _insider_strong_coordinate_descent, src/RcppExports.cpp:35-50), batched: nprob independent K-variable
  * elastic-net subproblems, one wavefront each, solved in covariance form from (XtX, Xty) — the design

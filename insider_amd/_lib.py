@@ -22,7 +22,7 @@ SYMBOLS = (
     "insider_hip_version", "insider_hip_last_error", "insider_hip_device_count", "insider_hip_create",
     "insider_hip_create_ex",
     "insider_hip_destroy", "insider_hip_set_shard", "insider_hip_set_option", "insider_hip_optimize",
-    "insider_hip_optimize_oneshot", "insider_hip_strong_cd", "insider_hip_masked_gram_cols",
+    "insider_hip_optimize_oneshot", "insider_hip_optimize_row", "insider_hip_optimize_col", "insider_hip_strong_cd", "insider_hip_masked_gram_cols",
     "insider_hip_masked_gram_rows", "insider_hip_get_profile", "insider_hip_get_sweeps", "insider_hip_last_cd_ms",
 )
 
@@ -63,6 +63,9 @@ def load():
     lib.insider_hip_optimize_oneshot.argtypes = [dp, C.c_int64, C.c_int64, C.POINTER(dp), dp, i32p, C.c_int, i32p,
                                                  u8p, u8p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                  C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_uint64, dp, dp, dp]
+    lib.insider_hip_optimize_row.argtypes = [C.c_void_p, C.POINTER(dp), dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+    lib.insider_hip_optimize_col.argtypes = [C.c_void_p, C.POINTER(dp), dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                             C.c_int, C.c_double, C.c_uint64, C.c_uint32]
     lib.insider_hip_strong_cd.argtypes = [dp, dp, dp, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
                                           C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, dp, i32p]
     lib.insider_hip_masked_gram_cols.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]

@@ -74,10 +74,8 @@ class InsiderData:
         self._cb = cb
         _lib.check(_lib.load().insider_hip_set_shard(self._h, int(gene_offset), int(rank), int(world), cb, None))
 
-    def optimize(self, cfd_factors, column_factor, latent_dim, lambda1=1.0, lambda2=1.0, alpha=0.1, tuning=1,
-                 global_tol=1e-10, sub_tol=1e-5, max_iter=10000, seed=DEFAULT_SEED, inc_continuous=0, traj_cap=4096):
-        lib = _lib.load()
-        K = int(latent_dim)
+    def _marshal(self, cfd_factors, column_factor, K, inc_continuous):
+        """F-ordered float64 views (or copies) of the factors plus the pointer array the C ABI takes."""
         A = []
         shapes = [int(L) for L in self.n_levels] + ([self.m] if inc_continuous else [])
         if len(cfd_factors) != len(shapes):
@@ -92,6 +90,38 @@ class InsiderData:
             raise InsiderError(_lib.ERR_ARG, f"column_factor must be {K} x {self.p}")
         Cw = Cm if (Cm.dtype == np.float64 and Cm.flags.f_contiguous) else _lib.f64(Cm).copy(order="F")
         Aptrs = (C.POINTER(C.c_double) * len(A))(*[_lib.ptr(a) for a in A])
+        return A, Cw, Aptrs
+
+    def optimize_row(self, cfd_factors, column_factor, cov, lambda_=1.0, tuning=1, inc_continuous=0):
+        """One row update of covariate `cov` (optimize_row, src/optimize.cpp:139-198 as called at :339); returns the
+        new L_cov x K factor and updates cfd_factors[cov] in place when it is an F-ordered float64 array."""
+        K = int(np.asarray(column_factor).shape[0])
+        A, Cw, Aptrs = self._marshal(cfd_factors, column_factor, K, inc_continuous)
+        _lib.check(_lib.load().insider_hip_optimize_row(self._h, Aptrs, _lib.ptr(Cw), int(inc_continuous), K, int(cov),
+                                                        float(lambda_), int(tuning)))
+        i = min(int(cov), len(A) - 1)
+        if A[i] is not cfd_factors[i] and isinstance(cfd_factors[i], np.ndarray):
+            cfd_factors[i][...] = A[i]
+        return A[i].copy()
+
+    def optimize_col(self, cfd_factors, column_factor, lambda_=1.0, alpha=0.1, tuning=1, tol=1e-5, seed=DEFAULT_SEED,
+                     it=0, inc_continuous=0):
+        """One column update (optimize_col, src/optimize.cpp:200-253 as called at :376); returns the new K x p factor
+        and updates column_factor in place when it is an F-ordered float64 array."""
+        K = int(np.asarray(column_factor).shape[0])
+        A, Cw, Aptrs = self._marshal(cfd_factors, column_factor, K, inc_continuous)
+        _lib.check(_lib.load().insider_hip_optimize_col(self._h, Aptrs, _lib.ptr(Cw), int(inc_continuous), K,
+                                                        float(lambda_), float(alpha), int(tuning), float(tol), int(seed),
+                                                        int(it)))
+        if Cw is not column_factor and isinstance(column_factor, np.ndarray):
+            column_factor[...] = Cw
+        return Cw.copy()
+
+    def optimize(self, cfd_factors, column_factor, latent_dim, lambda1=1.0, lambda2=1.0, alpha=0.1, tuning=1,
+                 global_tol=1e-10, sub_tol=1e-5, max_iter=10000, seed=DEFAULT_SEED, inc_continuous=0, traj_cap=4096):
+        lib = _lib.load()
+        K = int(latent_dim)
+        A, Cw, Aptrs = self._marshal(cfd_factors, column_factor, K, inc_continuous)
         traj = np.full((traj_cap, _lib.TRAJ_STRIDE), np.nan)
         tr, te, lo = C.c_double(), C.c_double(), C.c_double()
         rows, iters = C.c_int(), C.c_int()

@@ -541,6 +541,95 @@ void clear_events(insider_hip_handle *h)
     }
 }
 
+// host row/column factors -> padded device layout (the reference aliases R's memory, src/optimize.cpp:283-284)
+int upload_factors(insider_hip_handle *h, double *const *A, const double *C, int K)
+{
+    const int KP = h->KP;
+    for (int i = 0; i < h->c; ++i) {
+        const int L = h->n_levels[i];
+        HIPCHECK(hipMemcpyAsync(h->stage, A[i], (size_t)L * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_pack_A, dim3(cdiv(L * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, L, K, KP,
+                           h->Astack + (size_t)h->lvl_off[i] * KP);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));   // stage is reused
+    }
+    if (h->m > 0) {
+        HIPCHECK(hipMemcpyAsync(h->stage, A[h->c], (size_t)h->m * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_pack_A, dim3(cdiv(h->m * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, h->m, K,
+                           KP, h->Astack + (size_t)h->SLcat * KP);
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    HIPCHECK(hipMemcpyAsync(h->stage, C, (size_t)h->p * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(h->p * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, h->p, K,
+                       KP, h->C);
+    KCHECK();
+    return INSIDER_OK;
+}
+
+// device factors -> the caller's buffers (the reference returns copies AND has mutated its inputs in place, :413-421)
+int download_factors(insider_hip_handle *h, double *const *A, double *C, int K)
+{
+    const int KP = h->KP;
+    if (A) {
+        for (int i = 0; i < h->c; ++i) {
+            const int L = h->n_levels[i];
+            hipLaunchKernelGGL(k_unpack_A, dim3(cdiv(L * K, 256)), dim3(256), 0, h->stream,
+                               (const double *)(h->Astack + (size_t)h->lvl_off[i] * KP), L, K, KP, h->stage);
+            KCHECK();
+            HIPCHECK(hipMemcpyAsync(A[i], h->stage, (size_t)L * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+        }
+        if (h->m > 0) {
+            hipLaunchKernelGGL(k_unpack_A, dim3(cdiv(h->m * K, 256)), dim3(256), 0, h->stream,
+                               (const double *)(h->Astack + (size_t)h->SLcat * KP), h->m, K, KP, h->stage);
+            KCHECK();
+            HIPCHECK(hipMemcpyAsync(A[h->c], h->stage, (size_t)h->m * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(hipStreamSynchronize(h->stream));
+        }
+    }
+    if (C) {
+        hipLaunchKernelGGL(k_unpack_rows, dim3(cdiv(h->p * K, 256)), dim3(256), 0, h->stream, (const double *)h->C, h->p, K,
+                           KP, h->stage);
+        KCHECK();
+        HIPCHECK(hipMemcpyAsync(C, h->stage, (size_t)h->p * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+    }
+    return INSIDER_OK;
+}
+
+// C C' and S_i C' for the row step (src/optimize.cpp:332 and the unmasked part of :166,188)
+int launch_row_prep(insider_hip_handle *h)
+{
+    int rc = launch_gram(h, h->C, h->p, h->CCt);
+    if (rc) return rc;
+    const int KP = h->KP, LT = 256 / KP;
+    dim3 grid(h->sc_blocks, cdiv(h->SL, LT));
+    hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream, (const double *)h->S, h->SL, h->SLP,
+                       (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
+    KCHECK();
+    const int len = h->SL * KP;
+    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 256)), dim3(256), 0, h->stream, (const double *)h->sc_part,
+                       h->sc_blocks, len, h->SC);
+    KCHECK();
+    return INSIDER_OK;
+}
+
+int check_factor_args(insider_hip_handle *h, double *const *A, const double *C, int inc_continuous, int tuning)
+{
+    if (!h || !A || !C) return fail(INSIDER_ERR_ARG, "null argument");
+    if (tuning != 0 && tuning != 1)   // the reference prints and exit(1)s here (src/optimize.cpp:249-251)
+        return fail(INSIDER_ERR_ARG, "Parameter tuning should be either 0 or 1!");
+    if (inc_continuous != 0 && inc_continuous != 1)   // src/optimize.cpp:270-272
+        return fail(INSIDER_ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.");
+    if (inc_continuous == 1 && h->m == 0)
+        return fail(INSIDER_ERR_ARG, "inc_continuous = 1 needs a handle created with ctns_confounder (insider_hip_create_ex)");
+    if (inc_continuous == 0 && h->m > 0)
+        return fail(INSIDER_ERR_ARG, "this handle carries continuous covariates: pass inc_continuous = 1");
+    for (int i = 0; i < h->c + (h->m > 0 ? 1 : 0); ++i) if (!A[i]) return fail(INSIDER_ERR_ARG, "null row factor");
+    return INSIDER_OK;
+}
+
 }  // namespace
 
 // =================================================================================================================
@@ -843,43 +932,15 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
                          uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss, double *traj,
                          int traj_cap, int *out_traj_rows, int *out_iters)
 {
-    if (!h || !A || !C) return fail(INSIDER_ERR_ARG, "null argument");
-    if (tuning != 0 && tuning != 1)   // the reference prints and exit(1)s here (src/optimize.cpp:249-251)
-        return fail(INSIDER_ERR_ARG, "Parameter tuning should be either 0 or 1!");
-    if (inc_continuous != 0 && inc_continuous != 1)   // src/optimize.cpp:270-272
-        return fail(INSIDER_ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.");
-    if (inc_continuous == 1 && h->m == 0)
-        return fail(INSIDER_ERR_ARG, "inc_continuous = 1 needs a handle created with ctns_confounder (insider_hip_create_ex)");
-    if (inc_continuous == 0 && h->m > 0)
-        return fail(INSIDER_ERR_ARG, "this handle carries continuous covariates: pass inc_continuous = 1");
-    for (int i = 0; i < h->c + (h->m > 0 ? 1 : 0); ++i) if (!A[i]) return fail(INSIDER_ERR_ARG, "null row factor");
-    HIPCHECK(hipSetDevice(h->device));
-    int rc = ensure_workspace(h, K);
+    int rc = check_factor_args(h, A, C, inc_continuous, tuning);
     if (rc) return rc;
+    HIPCHECK(hipSetDevice(h->device));
+    if ((rc = ensure_workspace(h, K))) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     clear_events(h);
     const int KP = h->KP;
     const int masked = tuning == 1;
-    // ---- upload the inits (the reference aliases R's memory, src/optimize.cpp:283-284) --------------------------
-    for (int i = 0; i < h->c; ++i) {
-        const int L = h->n_levels[i];
-        HIPCHECK(hipMemcpyAsync(h->stage, A[i], (size_t)L * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_pack_A, dim3(cdiv(L * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, L, K, KP,
-                           h->Astack + (size_t)h->lvl_off[i] * KP);
-        KCHECK();
-        HIPCHECK(hipStreamSynchronize(h->stream));   // stage is reused
-    }
-    if (h->m > 0) {
-        HIPCHECK(hipMemcpyAsync(h->stage, A[h->c], (size_t)h->m * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_pack_A, dim3(cdiv(h->m * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, h->m, K,
-                           KP, h->Astack + (size_t)h->SLcat * KP);
-        KCHECK();
-        HIPCHECK(hipStreamSynchronize(h->stream));
-    }
-    HIPCHECK(hipMemcpyAsync(h->stage, C, (size_t)h->p * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_pack_rows, dim3(cdiv(h->p * KP, 256)), dim3(256), 0, h->stream, (const double *)h->stage, h->p, K,
-                       KP, h->C);
-    KCHECK();
+    if ((rc = upload_factors(h, A, C, K))) return rc;
 
     // ---- fit of the initial values (src/optimize.cpp:320-323) ----------------------------------------------------
     LossOut lo;
@@ -907,18 +968,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     while (iter <= max_iter) {                                                                  // :325
         if (h->verbose && iter % 10 == 0) printf("Iteration %u ---------------------------------\n", iter);
         // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
-        if ((rc = launch_gram(h, h->C, h->p, h->CCt))) return rc;                               // :332
-        {
-            const int LT = 256 / KP;
-            dim3 grid(h->sc_blocks, cdiv(h->SL, LT));
-            hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream, (const double *)h->S, h->SL, h->SLP,
-                               (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
-            KCHECK();
-            const int len = h->SL * KP;
-            hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 256)), dim3(256), 0, h->stream, (const double *)h->sc_part,
-                               h->sc_blocks, len, h->SC);
-            KCHECK();
-        }
+        if ((rc = launch_row_prep(h))) return rc;                                               // :332
         if (masked) if ((rc = launch_row_stats(h, true))) return rc;
         for (int i = 0; i < h->c; ++i)
             if ((rc = row_update(h, i, -1, masked, lambda1))) return rc;                        // :339
@@ -960,27 +1010,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         }
         ++iter;
     }
-    // ---- results back (the reference returns copies AND has mutated the inputs in place, :413-421) ---------------
-    for (int i = 0; i < h->c; ++i) {
-        const int L = h->n_levels[i];
-        hipLaunchKernelGGL(k_unpack_A, dim3(cdiv(L * K, 256)), dim3(256), 0, h->stream,
-                           (const double *)(h->Astack + (size_t)h->lvl_off[i] * KP), L, K, KP, h->stage);
-        KCHECK();
-        HIPCHECK(hipMemcpyAsync(A[i], h->stage, (size_t)L * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-    }
-    if (h->m > 0) {
-        hipLaunchKernelGGL(k_unpack_A, dim3(cdiv(h->m * K, 256)), dim3(256), 0, h->stream,
-                           (const double *)(h->Astack + (size_t)h->SLcat * KP), h->m, K, KP, h->stage);
-        KCHECK();
-        HIPCHECK(hipMemcpyAsync(A[h->c], h->stage, (size_t)h->m * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-    }
-    hipLaunchKernelGGL(k_unpack_rows, dim3(cdiv(h->p * K, 256)), dim3(256), 0, h->stream, (const double *)h->C, h->p, K,
-                       KP, h->stage);
-    KCHECK();
-    HIPCHECK(hipMemcpyAsync(C, h->stage, (size_t)h->p * K * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
+    if ((rc = download_factors(h, A, C, K))) return rc;
     if ((rc = check_fail_flag(h))) return rc;
     {
         unsigned long long bins[256];
@@ -1027,6 +1057,51 @@ int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *
     insider_hip_destroy(h);
     g_err = keep;
     return rc;
+}
+
+// One row update of one covariate, the reference's optimize_row() as optimize() calls it (src/optimize.cpp:339 with
+// :139-198): the residual is X minus the contributions of every OTHER covariate (their A_i as passed), A[cov] is
+// replaced by the per-level ridge solutions.  lambda = 0 on an interaction covariate with the other factors zero is
+// fit_interaction()'s arithmetic (src/fit_interaction.cpp:10-90).  cov >= c addresses continuous column cov - c
+// (optimize_continuous_v2, :76-137).
+int insider_hip_optimize_row(insider_hip_handle *h, double *const *A, const double *C, int inc_continuous, int K, int cov,
+                             double lambda, int tuning)
+{
+    int rc = check_factor_args(h, A, C, inc_continuous, tuning);
+    if (rc) return rc;
+    if (cov < 0 || cov >= h->c + (inc_continuous ? h->m : 0)) return fail(INSIDER_ERR_ARG, "covariate index out of range");
+    if (lambda < 0) return fail(INSIDER_ERR_ARG, "lambda must be >= 0");
+    HIPCHECK(hipSetDevice(h->device));
+    if ((rc = ensure_workspace(h, K))) return rc;
+    if ((rc = upload_factors(h, A, C, K))) return rc;
+    if ((rc = launch_row_prep(h))) return rc;
+    if (tuning == 1) if ((rc = launch_row_stats(h, false))) return rc;
+    if ((rc = launch_build_R(h))) return rc;
+    if (cov < h->c) rc = row_update(h, cov, -1, tuning, lambda);
+    else rc = row_update(h, 0, cov - h->c, tuning, lambda);
+    if (rc) return rc;
+    if ((rc = download_factors(h, A, nullptr, K))) return rc;
+    return check_fail_flag(h);
+}
+
+// One column update, the reference's optimize_col() as optimize() calls it (src/optimize.cpp:376 with :200-253):
+// every gene's elastic-net (alpha > 0, warm start C) or ridge (alpha == 0) regression of X on the row factor built
+// from A.  `iter` selects the sweep-order stream (include/insider_perm.h).
+int insider_hip_optimize_col(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K, double lambda,
+                             double alpha, int tuning, double tol, uint64_t seed, uint32_t iter)
+{
+    int rc = check_factor_args(h, A, C, inc_continuous, tuning);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(h->device));
+    if ((rc = ensure_workspace(h, K))) return rc;
+    if ((rc = upload_factors(h, A, C, K))) return rc;
+    if ((rc = phase_R(h))) return rc;
+    if (alpha != 0.0)
+        if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
+    if (tuning == 1) if ((rc = launch_col_stats(h, false))) return rc;
+    if ((rc = launch_col_solve(h, tuning, true, lambda, alpha, tol, 0, false))) return rc;
+    if ((rc = download_factors(h, nullptr, C, K))) return rc;
+    return check_fail_flag(h);
 }
 
 int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob, double lambda,

@@ -423,3 +423,84 @@ def test_caller_level_insider_tune_fit(oracle, tmp_path):
     assert relerr(obj["column_factor"], ref["column_factor"]) < 1e-6
     assert obj["test_rmse"] == pytest.approx(ref["test_rmse"], rel=1e-7)
     assert set(obj["cfd_matrices"]) == {"factor0", "factor1"}
+
+
+# ---- the block updates as stand-alone operators (optimize_row / optimize_col / fit_interaction arithmetic) ----------
+def _residual_without(w, A, C, cov):
+    """X minus the contribution of every covariate except `cov` (what optimize() hands optimize_row, :337-339)."""
+    others = sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]) if i != cov)
+    return w.X - (others @ C if not np.isscalar(others) else 0.0)
+
+
+@pytest.mark.parametrize("tuning", [1, 0])
+@pytest.mark.parametrize("kw", [dict(K=7), dict(K=20, n=130, p=110, level_counts=(9, 4, 3)), dict(K=33, with_na=True)])
+def test_optimize_row_operator(oracle, kw, tuning):
+    w = workloads.small(seed=41, **kw)
+    A, C = _rand_factors(w, 3)
+    M = w.M_train if tuning == 1 else np.ones_like(w.M_train)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    for cov in range(w.levels.shape[1]):
+        before = [a.copy() for a in A]
+        got = ds.optimize_row([a.copy(order="F") for a in A], C, cov, lambda_=w.lam, tuning=tuning)
+        ref = oracle.optimize_row(_residual_without(w, before, C, cov), M, before[cov], C, w.levels[:, cov], C @ C.T,
+                                  w.lam, tuning=tuning)
+        assert relerr(got, ref) < 1e-9, (cov, relerr(got, ref))
+    ds.close()
+
+
+def test_optimize_row_lambda_zero_is_fit_interaction(oracle):
+    """fit_interaction (src/fit_interaction.cpp:36-56): per interaction level, solve(sum C_nz C_nz', sum C_nz resid_nz)
+    with NO ridge term, on a residual that excludes the interaction factor itself."""
+    w = workloads.small(n=160, p=90, level_counts=(4, 3), K=5, seed=77, f=0.1)
+    levels = workloads.interaction_indicator(w.levels, [1, 2])      # interaction inserted 2nd (R/insider.R:40)
+    rng = np.random.default_rng(5)
+    n_levels = [int(levels[:, i].max()) for i in range(3)]
+    A = [np.asfortranarray(rng.standard_normal((L, w.K)) * 0.3) for L in n_levels]
+    C = np.asfortranarray(rng.standard_normal((w.K, w.X.shape[1])))
+    ds = api.InsiderData(w.X, levels, w.M_train, w.M_test)
+    got = ds.optimize_row([a.copy(order="F") for a in A], C, 1, lambda_=0.0, tuning=1)
+    ds.close()
+    resid = w.X - (A[0][levels[:, 0] - 1] + A[2][levels[:, 2] - 1]) @ C
+    want = np.zeros_like(A[1])
+    for l in range(n_levels[1]):                                   # direct form, as fit_interaction.cpp:44-54 states it
+        G = np.zeros((w.K, w.K))
+        q = np.zeros(w.K)
+        for r in np.nonzero(levels[:, 1] == l + 1)[0]:
+            nz = w.M_train[r] != 0
+            G += C[:, nz] @ C[:, nz].T
+            q += C[:, nz] @ resid[r, nz]
+        want[l] = np.linalg.solve(G, q)
+    assert relerr(got, want) < 1e-9
+    ref = oracle.optimize_row(resid, w.M_train, A[1], C, levels[:, 1], C @ C.T, 0.0, tuning=1)
+    assert relerr(got, ref) < 1e-9
+
+
+@pytest.mark.parametrize("alpha,tuning", [(0.4, 1), (0.0, 1), (0.3, 0), (0.0, 0), (1.0, 1)])
+def test_optimize_col_operator(oracle, alpha, tuning):
+    w = workloads.small(K=12, n=140, p=100, seed=43, with_na=True)
+    A, C = _rand_factors(w, 9)
+    M = w.M_train if tuning == 1 else np.ones_like(w.M_train)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    C_in = C.copy(order="F")
+    got = ds.optimize_col(A, C_in, lambda_=w.lam, alpha=alpha, tuning=tuning, tol=1e-9, seed=17, it=4)
+    sw = ds.sweeps()
+    ds.close()
+    assert np.array_equal(got, C_in)                              # updated in place, like the reference's mat&
+    ref, ref_sw = oracle.optimize_col(w.X, M, _R(w, A), C, w.lam, alpha, tuning=tuning, tol=1e-9, seed=17, it=4)
+    assert relerr(got, ref) < 1e-8, relerr(got, ref)
+    if alpha > 0:
+        assert abs(int(sw.sum()) - ref_sw) <= max(2, ref_sw // 200)
+
+
+def test_operators_reject_bad_arguments():
+    w = workloads.small(K=4, n=40, p=30)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    A, C = _cp(w)
+    with pytest.raises(_lib.InsiderError) as e:
+        ds.optimize_row(A, C, 5, lambda_=1.0)
+    assert e.value.status == _lib.ERR_ARG
+    with pytest.raises(_lib.InsiderError):
+        ds.optimize_row(A, C, 0, lambda_=-1.0)
+    with pytest.raises(_lib.InsiderError):
+        ds.optimize_col(A, C, tuning=2)
+    ds.close()
