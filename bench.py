@@ -175,7 +175,7 @@ def main():
                          "fp64_tflops": fl / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
                          "fp64_frac": fl / (gram_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gram_ms > 0 else 0.0,
                          "row_side_avg_launch_ms": prof["row_stats_ms"] / max(prof["row_stats_launches"], 1)},
-            "cd_kernel": {"kernel": "k_cd_cols_r16 (elastic-net coordinate sweeps, one 16-lane row group per gene, longest-first gene order)",
+            "cd_kernel": {"kernel": "k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)",
                           "avg_launch_ms": prof["cd_ms"] / max(prof["cd_launches"], 1),
                           "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,
                           "coordinate_updates_per_s": prof["sweeps"] * K / max(prof["cd_ms"] * 1e-3, 1e-9),

@@ -1,0 +1,412 @@
+// insider_cd_reg.hpp — register-resident elastic-net coordinate descent for K <= 32: four genes per wavefront,
+// the Gram matrix in VGPRs, no LDS.
+//
+// strong_coordinate_descent's sweep loop (src/coordinate_descent.cpp:86-114) is a K-step sequential recurrence per
+// gene that runs for hundreds to thousands of sweeps; it is bound by vector-instruction issue.  Layout: gene g owns
+// the 16-lane DPP row g of the wave; lane i of the row owns COORDINATES i and 16 + i for the whole solve (h, beta,
+// 1/(XtX_kk + l2)) and holds columns i and 16 + i of the gene's Gram matrix in registers (2 x KMAX doubles, zero
+// diagonal).  All genes follow the same coordinate order (include/insider_perm.h), so the coordinate k of a step is
+// wave-uniform: the step is dispatched through a computed jump (s_setpc_b64) into a table of 96-byte code blocks,
+// one per coordinate, whose byte offsets the order table holds per sweep position (34 dwords loaded into SGPRs at
+// the start of a sweep, indexed with s_movrels).  Inside block k everything is static — the Gram operand is the register holding G[u][k], the lane that
+// owns k is k % 16, and its (negated) increment reaches the row as the DPP row_newbcast:k%16 source operand of a
+// 64-bit v_fmac_f64 (gfx90a+ "DP ALU DPP").  Per step and wave (4 genes): 8 vector + 5 scalar instructions, no
+// memory or LDS access; the sweep is one inline-asm block (the compiler turns a C++ switch into a compare tree with
+// register copies at the merge).  Without LDS the occupancy is set by registers alone (REG_WAVES(KMAX) waves per
+// SIMD), where the LDS-resident variant (insider_cd_row16.hpp) held 5 waves per CU at K = 30.
+// Measured on MI355X (tools/ubench3.hip): every VALU instruction of the block, including the DPP fmac and v_mov_b64,
+// issues at ~2.15 ns per SIMD; a computed jump costs ~11 ns of single-wave latency.
+#pragma once
+
+namespace insider {
+
+constexpr int REG_ORDER_OFF = 128;   // byte offset of the block-offset dwords inside an order-table row
+static_assert(ORDER_ROW == 0x140, "the sweep prologue prefetches the next row at +0x140");
+constexpr int REG_BLOCK = 96;        // bytes between the code blocks of consecutive coordinates (see REG_BLOCK_HEAD)
+
+template <int SLOTS>
+struct RegState {
+    double h[SLOTS], beta[SLOTS], inv[SLOTS];
+};
+
+// ---- the sweep as one asm block -----------------------------------------------------------------------------------
+// Block for coordinate KK (slot s = KK / 16, owner lane it = KK % 16), src/coordinate_descent.cpp:91-110 in covariance
+// form: c = soft(h_s, la) * inv_s; dn = beta_s - c; beta_s[it] = c; h_u += bcast_it(dn) * G_u[KK].  soft(h, la) =
+// h - clamp(h, -la, la).  Screened-out coordinates and parked genes carry inv = beta = 0, i.e. a zero increment.
+// The sweep's 34 block offsets (positions 0..33; position K and beyond hold the exit block) are loaded into
+// s[64:97] at the start of the sweep and turned into the low words of the block addresses; the table of blocks
+// (REG_BLOCK bytes apart, placed with .org, which also asserts that no block outgrows its slot) starts on a 4 KiB
+// boundary and is shorter than 4 KiB, so it cannot straddle a 4 GiB boundary and the high word of every block address
+// is the same (vcc_hi, set once).  The block of position t fetches the address of the block of position t+1 with
+// s_movrels (M0 = t+1) into vcc_lo while the vector chain runs, and jumps.  Critical chain per step: min, max, add,
+// fma (dn), DPP fmac.  Hazards respected by construction: >= 2 instructions between the write of dn and its DPP read;
+// >= 1 between the write of M0 and s_movrels; exec is written by SALU only; nothing in a block writes vcc_hi.
+#define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
+    ".org Lc%= + 96*" #KK "\n"                                   \
+    "s_movrels_b32 vcc_lo, s64\n"                                \
+    "v_min_f64 %[c], %[" HS "], %[la]\n"                         \
+    "v_max_f64 %[c], %[c], -%[la]\n"                             \
+    "v_add_f64 %[c], %[" HS "], -%[c]\n"                         \
+    "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
+    "v_mul_f64 %[c], %[c], %[" IS "]\n"                          \
+    "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
+    "v_mov_b64 %[" BS "], %[c]\n"                                \
+    "s_mov_b64 exec, %[ex]\n"                                    \
+    "s_add_u32 m0, m0, 1\n"
+#define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
+#define REG_BLOCK2_LO(KK) \
+    REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) "s_setpc_b64 vcc\n"
+#define REG_BLOCK2_HI(KK, IT) \
+    REG_BLOCK_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) "s_setpc_b64 vcc\n"
+#define REG_BLOCK1(KK) REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) "s_setpc_b64 vcc\n"
+#define REG_ADDR4(A, B, C, D) \
+    "s_add_u32 s" #A ", s" #A ", s98\n s_add_u32 s" #B ", s" #B ", s98\n s_add_u32 s" #C ", s" #C ", s98\n s_add_u32 s" #D ", s" #D ", s98\n"
+#define REG_PROLOGUE                               \
+    "s_mov_b64 %[ex], exec\n"                      \
+    "s_mov_b32 %[sk], m0\n"                        \
+    "s_mov_b32 s63, %[sk]\n"                       \
+    "s_load_dwordx16 s[64:79], %[tb], 0x0\n"       \
+    "s_load_dwordx16 s[80:95], %[tb], 0x40\n"      \
+    "s_load_dwordx2 s[96:97], %[tb], 0x80\n"       \
+    "s_getpc_b64 s[98:99]\n"                       \
+    "Lr%=:\n"                                      \
+    "s_add_u32 s98, s98, Lc%=-Lr%=\n"              \
+    "s_addc_u32 s99, s99, 0\n"                     \
+    "s_mov_b32 m0, 1\n"                            \
+    "s_mov_b32 vcc_hi, s99\n"                      \
+    "s_waitcnt lgkmcnt(0)\n"                       \
+    REG_ADDR4(64, 65, 66, 67) REG_ADDR4(68, 69, 70, 71) REG_ADDR4(72, 73, 74, 75) REG_ADDR4(76, 77, 78, 79)            \
+    REG_ADDR4(80, 81, 82, 83) REG_ADDR4(84, 85, 86, 87) REG_ADDR4(88, 89, 90, 91) REG_ADDR4(92, 93, 94, 95)            \
+    "s_add_u32 s96, s96, s98\n s_add_u32 s97, s97, s98\n" \
+    "s_load_dword %[sk], %[tb], 0x140\n"           /* touch the next sweep's row (ORDER_ROW = 0x140 further): */ \
+    "s_load_dword %[p1], %[tb], 0x180\n"           /* its three lines are in the scalar cache when that sweep */ \
+    "s_load_dword %[p2], %[tb], 0x1c0\n"           /* starts; waited for in the exit block                    */ \
+    "s_mov_b32 vcc_lo, s64\n"                      \
+    "s_setpc_b64 vcc\n"                            \
+    ".p2align 12\n"                                \
+    "Lc%=:\n"
+#define REG_EPILOGUE(NBLK) ".org Lc%= + 96*" #NBLK "\n s_mov_b32 m0, s63\n s_waitcnt lgkmcnt(0)\n"   /* exit: M0 as on entry */
+#define REG_CLOBBERS                                                                                                     \
+    "vcc", "scc", "memory", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",   \
+        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",  \
+        "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+#define REG_GA(KK) [ga##KK] "v"(G[0][KK]),
+#define REG_GB(KK) [gb##KK] "v"(G[1][KK]),
+#define REG_HI16(KK, IT) REG_BLOCK2_HI(KK, IT)
+#define REG_LIST_LO(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+// coordinates 16 .. KMAX-1, as (coordinate) for operand lists and (coordinate, owner lane) for blocks
+#define REG_HI_18(F) F(16) F(17)
+#define REG_HI_20(F) REG_HI_18(F) F(18) F(19)
+#define REG_HI_22(F) REG_HI_20(F) F(20) F(21)
+#define REG_HI_24(F) REG_HI_22(F) F(22) F(23)
+#define REG_HI_26(F) REG_HI_24(F) F(24) F(25)
+#define REG_HI_28(F) REG_HI_26(F) F(26) F(27)
+#define REG_HI_30(F) REG_HI_28(F) F(28) F(29)
+#define REG_HI_32(F) REG_HI_30(F) F(30) F(31)
+#define REG_HB_18(F) F(16, 0) F(17, 1)
+#define REG_HB_20(F) REG_HB_18(F) F(18, 2) F(19, 3)
+#define REG_HB_22(F) REG_HB_20(F) F(20, 4) F(21, 5)
+#define REG_HB_24(F) REG_HB_22(F) F(22, 6) F(23, 7)
+#define REG_HB_26(F) REG_HB_24(F) F(24, 8) F(25, 9)
+#define REG_HB_28(F) REG_HB_26(F) F(26, 10) F(27, 11)
+#define REG_HB_30(F) REG_HB_28(F) F(28, 12) F(29, 13)
+#define REG_HB_32(F) REG_HB_30(F) F(30, 14) F(31, 15)
+
+// tb: this sweep's block-offset dwords (order-table row + REG_ORDER_OFF); la in SGPRs
+#if defined(__HIP_DEVICE_COMPILE__)   // gfx950 assembly: hipcc's host pass must not parse it
+#define REG_DEFINE_SWEEP2(KMAX)                                                                                          \
+    __device__ __forceinline__ void reg_sweep(RegState<2> &S, const double (&G)[2][KMAX], double la, const uint32_t *tb) \
+    {                                                                                                                    \
+        double c, dn;                                                                                                    \
+        int sk, p1, p2;                                                                                                  \
+        uint64_t ex;                                                                                                     \
+        const uint64_t lm = 0x0001000100010001ull;                                                                       \
+        asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                       \
+                     : [h0] "+v"(S.h[0]), [h1] "+v"(S.h[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), [c] "=&v"(c),   \
+                       [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [ex] "=&s"(ex)                    \
+                     : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(      \
+                           S.inv[0]),                                                                                    \
+                       [i1] "v"(S.inv[1]), [la] "s"(la), [tb] "s"(tb), [lm] "s"(lm)                                      \
+                     : REG_CLOBBERS);                                                                                    \
+    }
+#else
+#define REG_DEFINE_SWEEP2(KMAX) \
+    __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][KMAX], double, const uint32_t *) {}
+#endif
+REG_DEFINE_SWEEP2(18)
+REG_DEFINE_SWEEP2(20)
+REG_DEFINE_SWEEP2(22)
+REG_DEFINE_SWEEP2(24)
+REG_DEFINE_SWEEP2(26)
+REG_DEFINE_SWEEP2(28)
+REG_DEFINE_SWEEP2(30)
+REG_DEFINE_SWEEP2(32)
+
+__device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][16], double la, const uint32_t *tb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double c, dn;
+    int sk, p1, p2;
+    uint64_t ex;
+    const uint64_t lm = 0x0001000100010001ull;
+    asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16)
+                 : [h0] "+v"(S.h[0]), [b0] "+v"(S.beta[0]), [c] "=&v"(c), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
+                   [p2] "=&s"(p2), [ex] "=&s"(ex)
+                 : REG_LIST_LO(REG_GA)[i0] "v"(S.inv[0]), [la] "s"(la), [tb] "s"(tb), [lm] "s"(lm)
+                 : REG_CLOBBERS);
+#endif
+}
+
+// waves per SIMD the register budget of an instantiation is sized for (512 VGPRs per SIMD lane)
+__host__ __device__ constexpr int reg_waves(int KMAX) { return KMAX <= 16 ? 4 : KMAX <= 22 ? 4 : 3; }
+// smallest instantiated KMAX >= K
+__host__ __device__ constexpr int reg_kmax(int K) { return K <= 16 ? 16 : (K + 1) & ~1; }
+
+// acc[u] -= sum_{m < K} G[u][m] * v_m  (v in coordinate order)
+template <int SLOTS, int KMAX>
+__device__ __forceinline__ void reg_gemv(double (&acc)[SLOTS], const double (&v)[SLOTS], const double (&G)[SLOTS][KMAX],
+                                         int K)
+{
+#define REG_G(M)                                                                                        \
+    if constexpr ((M) < KMAX) {                                                                         \
+        if ((M) < K) {                                                                                  \
+            const double vm = row_bcast<(M) & 15>(v[(M) >> 4]);                                         \
+            _Pragma("unroll") for (int u = 0; u < SLOTS; ++u) acc[u] = fma(-vm, G[u][(M)], acc[u]);     \
+        }                                                                                               \
+    }
+    R16_UNROLL32(REG_G)
+#undef REG_G
+}
+
+// LDS doubles per wave: per lane and slot D = XtX_kk + l2, the sweep-start beta and w = beta D - h, and the solution
+// (values that are not needed inside the sweep live here so that the registers hold only the Gram columns and the
+// sweep state)
+constexpr int REG_STASH = 4 * 2 * 64;
+
+// The solver.  G: columns 16u + i of the row's Gram matrix (zero diagonal).  q, Gll, beta: coordinate 16u + i of
+// gene `row`; beta = warm start in, solution out.  gene_ok: the row holds a gene.  stash: this wave's REG_STASH
+// doubles of LDS.  Returns the row's sweep count.
+// Loss change of a sweep (:112-114) from per-coordinate start/end values: with g = h - beta XtX_kk (the gradient part
+// Xty - XtX beta) the exact change is sum_l [-1/2 db (g0 + g1) + 1/2 l2 (b1^2 - b0^2) + la (|b1| - |b0|)]
+// = sum_l [1/2 db (w0 + w1) + la (|b1| - |b0|)],  w = beta (XtX_kk + l2) - h;  the end values of one sweep are the
+// start values of the next.  Lanes without a coordinate carry h = beta = 0 and contribute nothing.
+template <int SLOTS, int KMAX>
+__device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, const double (&q)[SLOTS],
+                                      const double (&Gll)[SLOTS], double (&beta)[SLOTS], bool gene_ok, const CdParams &P,
+                                      int lane, double *stash)
+{
+    const int row = lane >> 4, i = lane & 15;
+    const double la = P.la, l2 = P.l2;
+    const uint64_t rowmask = 0xffffull << (16 * row);
+    double *s_d = stash + lane, *s_b = s_d + 128, *s_w = s_d + 256, *s_out = s_d + 384;   // [slot * 64]
+    // ---- strong rule and start values (:74-80) ---------------------------------------------------------------
+    double aq = 0.0;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) aq = fmax(aq, (gene_ok && 16 * u + i < K) ? fabs(q[u]) : 0.0);
+    const double thr = P.alpha * (2.0 * P.lambda - row16_max(aq));                        // :74
+    RegState<SLOTS> S;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const bool valid = gene_ok && 16 * u + i < K;
+        const bool active = valid && !(fabs(q[u]) < thr);
+        const double D = (valid ? Gll[u] : 1.0) + l2;
+        S.beta[u] = active ? beta[u] : 0.0;                                               // :78
+        S.inv[u] = active ? 1.0 / D : 0.0;
+        S.h[u] = valid ? q[u] : 0.0;
+        s_d[64 * u] = D;
+        s_out[64 * u] = S.beta[u];
+    }
+    reg_gemv<SLOTS, KMAX>(S.h, S.beta, G, K);                                             // :79 h = q - offdiag(XtX) beta
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        s_b[64 * u] = S.beta[u];
+        s_w[64 * u] = fma(S.beta[u], s_d[64 * u], -S.h[u]);
+    }
+
+    bool run = gene_ok;
+    int sweep = 0, my_sweeps = 0;
+    while (__any(run)) {
+        // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
+        reg_sweep(S, G, la, reinterpret_cast<const uint32_t *>(P.order + (size_t)sweep * ORDER_ROW + REG_ORDER_OFF));
+        ++sweep;
+        // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
+        double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const double beta0 = s_b[64 * u];
+            const double w1 = fma(S.beta[u], s_d[64 * u], -S.h[u]);
+            acc = fma(S.beta[u] - beta0, w1 + s_w[64 * u], acc);
+            acc1 += fabs(S.beta[u]) - fabs(beta0);
+            s_b[64 * u] = S.beta[u];
+            s_w[64 * u] = w1;
+        }
+        const double dloss = row16_sum(fma(la, acc1, 0.5 * acc));
+        if (run) {
+            bool finish = sweep >= P.max_sweeps;
+            if (!finish && !(fabs(dloss) > P.tol)) {                                      // :114
+                bool anyv = false;
+#pragma unroll
+                for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
+                    const bool viol = gene_ok && 16 * u + i < K && S.inv[u] == 0.0 && fabs(S.h[u]) > la;
+                    if (viol) S.inv[u] = 1.0 / s_d[64 * u];                               // :123
+                    anyv = anyv || viol;
+                }
+                if ((__ballot(anyv) & rowmask) == 0) finish = true;                       // :120-121
+            }
+            if (finish) {   // park the row: zero increments from now on
+                my_sweeps = sweep;
+#pragma unroll
+                for (int u = 0; u < SLOTS; ++u) {
+                    s_out[64 * u] = S.beta[u];
+                    S.beta[u] = 0.0;
+                    S.inv[u] = 0.0;
+                }
+                run = false;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) beta[u] = (gene_ok && 16 * u + i < K) ? s_out[64 * u] : 0.0;
+    return my_sweeps;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel: column update with the register-resident solver (K <= 32); same contract as k_cd_cols
+// ---------------------------------------------------------------------------------------------
+template <int SLOTS, int KMAX>
+__global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
+{
+    const int lane = threadIdx.x;
+    const int row = lane >> 4, i = lane & 15;
+    const int K = a.K, KP = a.KP;
+    const int slot = blockIdx.x * 4 + row;
+    const int j = slot < a.p ? (a.gene_perm ? a.gene_perm[slot] : slot) : a.p;
+    const bool gene = j < a.p;
+    __shared__ double stash[REG_STASH];
+    const double *st = (a.stat && gene) ? a.stat + (size_t)j * a.stat_len : nullptr;
+    // XtX_j = R'R - complement (src/optimize.cpp:218-219), or the shared R'R (:234); zero diagonal in registers.
+    // Branch-free: without statistics the subtrahend is read from R'R itself (any valid memory) and scaled by 0.
+    const double *stp = st ? st : a.RtR;
+    const double ms = st ? 1.0 : 0.0;
+    double G[SLOTS][KMAX], q[SLOTS], Gll[SLOTS], beta[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int c = 16 * u + i;
+        const bool ok = gene && c < K;
+        Gll[u] = 1.0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            // element (k, c) of the lower-block-stored statistics (stat_index with the block pair known statically)
+            const int bk = k >> 4;
+            const int si = bk >= u ? (bk * (bk + 1) / 2 + u) * 256 + (k & 15) * 16 + i
+                                   : (u * (u + 1) / 2 + bk) * 256 + i * 16 + (k & 15);
+            const double v = fma(-ms, stp[si], a.RtR[k * KP + c]);
+            G[u][k] = (ok && k < K && k != c) ? v : 0.0;
+        }
+        q[u] = 0.0;
+        beta[u] = 0.0;
+        if (ok) {
+            Gll[u] = a.RtR[c * KP + c];
+            if (st) Gll[u] -= st[stat_index(c, c)];
+            q[u] = a.Qfull[(size_t)j * KP + c];                                          // :222,235 via level sums
+            if (st) q[u] -= st[stat_index(KP - 1, c)];                                   // minus the held-out part
+            beta[u] = a.C[(size_t)j * KP + c];
+        }
+    }
+    if (a.mode == COL_CD) {                                                              // :228,246
+        const int sweeps = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, gene, a.cd, lane, stash);
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+            if (gene && 16 * u + i < K) a.C[(size_t)j * KP + 16 * u + i] = beta[u];
+        if (gene && i == 0) {
+            a.sweeps[j] = sweeps;
+            if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
+        }
+    }
+    if (!a.checkpoint) return;
+    // ---- loss statistics with the (updated) column: fresh g = q - XtX beta ---------------------------------------------
+    double g[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) g[u] = (gene && 16 * u + i < K) ? q[u] - Gll[u] * beta[u] : 0.0;
+    reg_gemv<SLOTS, KMAX>(g, beta, G, K);
+    double t_bqg = 0.0, t_b2 = 0.0, t_b1 = 0.0, t_te = 0.0;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        if (gene && 16 * u + i < K) {
+            t_bqg += beta[u] * (q[u] + g[u]);
+            t_b2 += beta[u] * beta[u];
+            t_b1 += fabs(beta[u]);
+        }
+    }
+    if (a.test_from_stats && st) {
+        // sum_test (x - r'b)^2 = sum_held x^2 - 2 b'qc + b'(R'R b) - b'(q - g)      (see k_cd_cols)
+        double rb[SLOTS];
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) rb[u] = 0.0;
+#define R16_D(M) r16_dense_mv_step<SLOTS, M>(rb, beta, a.RtR, KP, K, i, gene);
+        R16_UNROLL32(R16_D)
+#undef R16_D
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int c = 16 * u + i;
+            if (gene && c < K) t_te += beta[u] * (rb[u] - (q[u] - g[u]) - 2.0 * st[stat_index(KP - 1, c)]);
+        }
+    }
+    const double bqg = row16_sum(t_bqg), sb2 = row16_sum(t_b2), sb1 = row16_sum(t_b1), te = row16_sum(t_te);
+    if (gene && i == 0) {
+        a.sse_train[j] = a.yy[j] - bqg;
+        a.b2[j] = sb2;
+        a.b1[j] = sb1;
+        if (a.test_from_stats) a.sse_test[j] = st ? st[stat_index(KP - 1, KP - 1)] + te : 0.0;
+    }
+}
+
+// stand-alone batch form (insider_hip_strong_cd) on dense (XtX, Xty)
+template <int SLOTS, int KMAX>
+__global__ void __launch_bounds__(64, reg_waves(KMAX))
+k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, const double *__restrict__ wstart, int K,
+               int64_t nprob, CdParams cd, double *__restrict__ beta_out, int *__restrict__ sweeps_out)
+{
+    const int lane = threadIdx.x;
+    const int row = lane >> 4, i = lane & 15;
+    const int64_t b = (int64_t)blockIdx.x * 4 + row;
+    const bool prob = b < nprob;
+    __shared__ double stash[REG_STASH];
+    const double *Gb = XtX + (size_t)(prob ? b : 0) * K * K;
+    double G[SLOTS][KMAX], q[SLOTS], Gll[SLOTS], beta[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int c = 16 * u + i;
+        const bool ok = prob && c < K;
+        const int cc = c < K ? c : 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const double v = Gb[(size_t)(k < K ? k : 0) * K + cc];
+            G[u][k] = (ok && k < K && k != c) ? v : 0.0;
+        }
+        Gll[u] = ok ? XtX[(size_t)b * K * K + (size_t)c * K + c] : 1.0;
+        q[u] = ok ? Xty[(size_t)b * K + c] : 0.0;
+        beta[u] = ok ? wstart[(size_t)b * K + c] : 0.0;
+    }
+    const int sw = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, prob, cd, lane, stash);
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u)
+        if (prob && 16 * u + i < K) beta_out[(size_t)b * K + 16 * u + i] = beta[u];
+    if (prob && i == 0 && sweeps_out) sweeps_out[b] = sw;
+}
+
+// host-side dispatch over the instantiated (SLOTS, KMAX) pairs: F is a generic lambda taking two integral constants
+#define REG_DISPATCH(K, CALL)                                      \
+    switch (reg_kmax(K)) {                                         \
+        case 16: { constexpr int SL_ = 1, KM_ = 16; CALL; } break; \
+        case 18: { constexpr int SL_ = 2, KM_ = 18; CALL; } break; \
+        case 20: { constexpr int SL_ = 2, KM_ = 20; CALL; } break; \
+        case 22: { constexpr int SL_ = 2, KM_ = 22; CALL; } break; \
+        case 24: { constexpr int SL_ = 2, KM_ = 24; CALL; } break; \
+        case 26: { constexpr int SL_ = 2, KM_ = 26; CALL; } break; \
+        case 28: { constexpr int SL_ = 2, KM_ = 28; CALL; } break; \
+        case 30: { constexpr int SL_ = 2, KM_ = 30; CALL; } break; \
+        default: { constexpr int SL_ = 2, KM_ = 32; CALL; } break; \
+    }
+
+}  // namespace insider

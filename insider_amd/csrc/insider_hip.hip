@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -295,12 +296,12 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     if (h->order_rows < max_sweeps) {
         if (h->order) (void)hipFree(h->order);
         h->order = nullptr;
-        int rc = dmalloc(&h->order, (size_t)max_sweeps * ORDER_ROW);
+        int rc = dmalloc(&h->order, (size_t)(max_sweeps + 1) * ORDER_ROW);   // + one row: the CD kernel prefetches ahead
         if (rc) return rc;
         h->order_rows = max_sweeps;
     }
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)max_sweeps * 64, 256)), dim3(256), 0, h->stream, seed, iter, K,
-                       max_sweeps, order_mode, K * 8, h->order);
+                       max_sweeps, order_mode, K * 8, reg_kmax(K), h->order);
     KCHECK();
     return INSIDER_OK;
 }
@@ -363,6 +364,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.cd.lambda = lambda;
         a.cd.alpha = alpha;
         a.cd.tol = tol;
+        a.cd.la = lambda * alpha;
+        a.cd.l2 = lambda * (1.0 - alpha);
         a.cd.max_sweeps = h->max_sweeps;
         a.cd.order = h->order;
         a.sse_train = h->sse_train;
@@ -374,9 +377,11 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.sweep_bins = (timed && solve) ? h->sweep_total : nullptr;
         a.gene_perm = (solve && h->have_perm) ? h->gene_perm : nullptr;
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
-        if (h->cd_variant == 0 && h->K <= 16)
+        if (h->cd_variant == 0 && h->K <= 32) {
+            REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a));
+        } else if (h->cd_variant == 2 && h->K <= 16)
             hipLaunchKernelGGL((k_cd_cols_r16<1>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
-        else if (h->cd_variant == 0 && h->K <= 32)
+        else if (h->cd_variant == 2 && h->K <= 32)
             hipLaunchKernelGGL((k_cd_cols_r16<2>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
         else if (h->K <= 16) hipLaunchKernelGGL((k_cd_cols<16, 4>), dim3(cdiv(h->p, 16)), dim3(256), 0, h->stream, a);
         else if (h->K <= 32) hipLaunchKernelGGL((k_cd_cols<32, 2>), dim3(cdiv(h->p, 4)), dim3(128), 0, h->stream, a);
@@ -922,7 +927,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
     else if (s == "force_allreduce") h->force_allreduce = (int)value;   // call the all-reduce callback even when world == 1
-    else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = row16 (4 genes per wave, K <= 32), 1 = group kernel
+    else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
 }
@@ -1127,26 +1132,37 @@ int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *ws
     HIPCHECK(hipMemcpy(dw, wstart, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
     const int ms = max_sweeps < 1 ? 1 : max_sweeps;
     uint8_t *dord = nullptr;
-    if ((rc = dmalloc(&dord, (size_t)ms * ORDER_ROW))) return rc;
+    if ((rc = dmalloc(&dord, (size_t)(ms + 1) * ORDER_ROW))) return rc;   // + one row: the CD kernel prefetches ahead
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)ms * 64, 256)), dim3(256), 0, 0, seed, iter, K, ms, order_mode, K * 8,
-                       dord);
+                       reg_kmax(K), dord);
     KCHECK();
     CdParams cd;
     cd.lambda = lambda;
     cd.alpha = alpha;
     cd.tol = tol;
+    cd.la = lambda * alpha;
+    cd.l2 = lambda * (1.0 - alpha);
     cd.max_sweeps = ms;
     cd.order = dord;
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
     HIPCHECK(hipEventRecord(e0, 0));
+    // debugging knob: INSIDER_CD_VARIANT=2 runs the LDS-resident row16 solver instead of the register-resident one
+    const char *var = std::getenv("INSIDER_CD_VARIANT");
+    const bool lds_variant = var && std::atoi(var) == 2;
     const size_t r16_bytes = (size_t)r16_lds_doubles(K) * sizeof(double);
-    if (K <= 16) hipLaunchKernelGGL((k_cd_batch_r16<1>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, (const double *)dG,
-                                    (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
-    else if (K <= 32) hipLaunchKernelGGL((k_cd_batch_r16<2>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0,
-                                         (const double *)dG, (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
-    else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, (const double *)dG,
+    if (K <= 16 && lds_variant)
+        hipLaunchKernelGGL((k_cd_batch_r16<1>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, (const double *)dG,
+                           (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+    else if (K <= 32 && lds_variant)
+        hipLaunchKernelGGL((k_cd_batch_r16<2>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, (const double *)dG,
+                           (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+    else if (K <= 32) {
+        REG_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0,
+                                           (const double *)dG, (const double *)dq, (const double *)dw, K, nprob, cd, db,
+                                           ds));
+    } else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, (const double *)dG,
                             (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
     KCHECK();
     HIPCHECK(hipEventRecord(e1, 0));

@@ -30,7 +30,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int WAVE = 64;
 constexpr int CHUNK = 128;      // elements per streaming step (2 per lane); line pitches are multiples of it
 
-constexpr int ORDER_ROW = 128;   // bytes per sweep in the coordinate-order table (see k_order_table)
+constexpr int ORDER_ROW = 320;   // bytes per sweep in the coordinate-order table (see k_order_table)
 
 constexpr int CODE_TRAIN = 1;   // bit 0 of a mask code: entry is in the train set
 constexpr int CODE_TEST = 2;    // bit 1: entry is in the test set (neither bit: NA)
@@ -192,6 +192,7 @@ __device__ __forceinline__ void acc_to_lds(const d4 (&acc)[Geo<NB>::NBLK], doubl
 //                                             dL = -1/2 sum_l db_l (g_l + g'_l) + penalties(b') - penalties(b)
 struct CdParams {
     double lambda, alpha, tol;
+    double la, l2;          // lambda * alpha, lambda * (1 - alpha): formed on the host so that they arrive in SGPRs
     int max_sweeps;
     const uint8_t *order;   // [max_sweeps][ORDER_ROW], see k_order_table
 };
@@ -343,9 +344,11 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
 
 // Order table, one row of ORDER_ROW bytes per sweep s < nsweeps: bytes [0, 64): the K coordinates in ascending key
 // order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
-// the row16 kernel, K <= 32).  One thread per (sweep, coordinate): rank by counting.
+// the row16 kernel, K <= 32); bytes [128, 320): 48 uint32 = coordinate * 96 for positions < K and exit_block * 96
+// beyond (code-block offsets of the register-resident kernel, insider_cd_reg.hpp).  One thread per (sweep,
+// coordinate): rank by counting.
 __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
-                                                     int pitch_bytes, uint8_t *__restrict__ order)
+                                                     int pitch_bytes, int exit_block, uint8_t *__restrict__ order)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = t >> 6, l = t & 63;
@@ -354,6 +357,7 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     if (l >= K) {
         row[l] = 0;
         if (l < 32) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
+        if (l < 48) reinterpret_cast<uint32_t *>(row + 128)[l] = (uint32_t)exit_block * 96u;
         return;
     }
     int rank = l;
@@ -365,6 +369,7 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     }
     row[rank] = (uint8_t)l;
     if (rank < 32) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
+    if (rank < 48) reinterpret_cast<uint32_t *>(row + 128)[rank] = (uint32_t)l * 96u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1287,3 +1292,4 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
 }  // namespace insider
 
 #include "insider_cd_row16.hpp"
+#include "insider_cd_reg.hpp"
