@@ -62,7 +62,7 @@ struct CovTables {   // per covariate, device
 };
 // continuous columns share one table: a single pseudo-level whose members are all samples, in 16-sample chunks
 
-constexpr int LEVEL_CHUNK = 16;
+constexpr int LEVEL_CHUNK = 4;   // member samples per wave of k_level_partial
 
 }  // namespace
 
@@ -96,6 +96,7 @@ struct insider_hip_handle {
     int K = 0, NB = 0, KP = 0, nseg = 1, seg_len = 0;
     double *Astack = nullptr, *R = nullptr, *C = nullptr, *RtR = nullptr, *CCt = nullptr, *Qfull = nullptr, *SC = nullptr;
     double *stat = nullptr, *stat_col = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
+    double *lvl_sum = nullptr;
     double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
     int *sweeps = nullptr, *failflag = nullptr;
     unsigned long long *sweep_total = nullptr;
@@ -125,7 +126,7 @@ namespace {
 void free_workspace(insider_hip_handle *h)
 {
     double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
-                       &h->sc_part, &h->lvl_part, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
+                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->sweeps) (void)hipFree(h->sweeps);
@@ -176,6 +177,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->gram_part, (size_t)std::max(h->gram_blocks_p, h->gram_blocks_n) * KP * KP))) return rc;
     if ((rc = dmalloc(&h->sc_part, (size_t)h->sc_blocks * h->SL * KP))) return rc;
     if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP + 2)))) return rc;
+    if ((rc = dmalloc(&h->lvl_sum, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2)))) return rc;
     if ((rc = dmalloc(&h->eq, (size_t)h->max_L * (KP * KP + KP)))) return rc;
     if ((rc = dmalloc(&h->sse_train, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sse_test, (size_t)h->p))) return rc;
@@ -244,7 +246,7 @@ int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *ou
     }
     KCHECK();
     const int len = h->KP * h->KP;
-    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 256)), dim3(256), 0, h->stream, h->gram_part, nb, len, out);
+    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 16)), dim3(256), 0, h->stream, h->gram_part, nb, len, out);
     KCHECK();
     return INSIDER_OK;
 }
@@ -462,8 +464,7 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
     la.Astack = h->Astack;
     la.part = h->lvl_part;
     LevelReduceArgs ra;
-    ra.part = h->lvl_part;
-    ra.lvl_chunk_ptr = ct.lvl_chunk_ptr;
+    ra.part = h->lvl_sum;
     ra.L = ct.L;
     ra.K = h->K;
     ra.CCt = h->CCt;
@@ -472,7 +473,10 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
     ra.eq = h->eq;
     NB_DISPATCH(h->NB, {
         (void)WPB_;
+        constexpr int PLEN = Geo<NB_>::STAT + 2 * Geo<NB_>::KP + 2;
         hipLaunchKernelGGL((k_level_partial<NB_>), dim3(ct.nchunks), dim3(64), 0, h->stream, la);
+        hipLaunchKernelGGL(k_level_sum, dim3(cdiv(PLEN, 16), ct.L), dim3(256), 0, h->stream, (const double *)h->lvl_part,
+                           (const int *)ct.lvl_chunk_ptr, PLEN, h->lvl_sum);
         hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(ct.L), dim3(64), 0, h->stream, ra);
     });
     KCHECK();
@@ -614,7 +618,7 @@ int launch_row_prep(insider_hip_handle *h)
                        (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
     KCHECK();
     const int len = h->SL * KP;
-    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 256)), dim3(256), 0, h->stream, (const double *)h->sc_part,
+    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 16)), dim3(256), 0, h->stream, (const double *)h->sc_part,
                        h->sc_blocks, len, h->SC);
     KCHECK();
     return INSIDER_OK;

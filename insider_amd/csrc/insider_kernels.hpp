@@ -822,14 +822,25 @@ __global__ void __launch_bounds__(256) k_gram_partial(const double *__restrict__
     }
 }
 
-// out[o] = sum_b part[b][o]  (fixed order: bitwise reproducible)
-__global__ void k_sum_partials(const double *__restrict__ part, int nblk, int len, double *__restrict__ out)
+// out[o] = sum_b part[b][o]  (fixed order: bitwise reproducible).  Block = 16 outputs x 16 strided groups of partial
+// blocks (short dependent chains), then the 16 group sums are added in group order.
+__global__ void __launch_bounds__(256) k_sum_partials(const double *__restrict__ part, int nblk, int len,
+                                                      double *__restrict__ out)
 {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= len) return;
+    __shared__ double red[16][17];
+    const int ol = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + ol;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * len + o];
-    out[o] = s;
+    if (o < len)
+        for (int b = g; b < nblk; b += 16) s += part[(size_t)b * len + o];
+    red[g][ol] = s;
+    __syncthreads();
+    if (g == 0 && o < len) {
+        double t = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) t += red[m][ol];
+        out[o] = t;
+    }
 }
 
 // Qfull[j][k] = sum_l Astack[l][k] * S[j][l]     (== R' x_j over all samples: x summed per level first)
@@ -985,11 +996,32 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
     if (lane == 0) { out[STAT + 2 * KP] = w2sum; out[STAT + 2 * KP + 1] = 0.0; }
 }
 
-// Stage 2 (one wave per level): sum the level's chunk partials in fixed order and form this rank's share of
+// Stage 2a: per level, the sum of its chunk partials (vectors of `len` doubles) in a fixed order: block = 16 outputs x
+// 16 strided groups of chunks, then the 16 group sums in group order.  grid = (ceil(len / 16), L).
+__global__ void __launch_bounds__(256) k_level_sum(const double *__restrict__ part, const int *__restrict__ lvl_chunk_ptr,
+                                                   int len, double *__restrict__ out /*[L][len]*/)
+{
+    __shared__ double red[16][17];
+    const int ol = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + ol, l = blockIdx.y;
+    const int c0 = lvl_chunk_ptr[l], c1 = lvl_chunk_ptr[l + 1];
+    double s = 0.0;
+    if (o < len)
+        for (int ch = c0 + g; ch < c1; ch += 16) s += part[(size_t)ch * len + o];
+    red[g][ol] = s;
+    __syncthreads();
+    if (g == 0 && o < len) {
+        double t = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) t += red[m][ol];
+        out[(size_t)l * len + o] = t;
+    }
+}
+
+// Stage 2b (one wave per level): from the level's summed partials form this rank's share of
 // the normal equations: eq[l] = {XtX (KP x KP, full symmetric, no ridge term), Xty (KP)}.
 struct LevelReduceArgs {
-    const double *part;
-    const int *lvl_chunk_ptr;   // per level: chunk range
+    const double *part;         // [L][STAT + 2*KP + 2]: the level sums of k_level_sum
     int L, K;
     const double *CCt;          // KP x KP (this rank's gene slab)
     const double *SC;           // [SL][KP]: (S C') rows; this covariate starts at sc_off
@@ -1009,18 +1041,14 @@ __global__ void __launch_bounds__(64) k_level_reduce(LevelReduceArgs a)
     const bool valid = lane < K;
     const int sub = lane >> 4, c16 = lane & 15;
     d4 h[NBLK];
+    double v = 0.0, ssum = 0.0;
+    const double *src = a.part + (size_t)l * (STAT + 2 * KP + 2);
+    const double cnt = src[STAT + 2 * KP];
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b) h[b] = d4{0.0, 0.0, 0.0, 0.0};
-    double v = 0.0, ssum = 0.0, cnt = 0.0;
-    for (int ch = a.lvl_chunk_ptr[l]; ch < a.lvl_chunk_ptr[l + 1]; ++ch) {
-        const double *src = a.part + (size_t)ch * (STAT + 2 * KP + 2);
-        cnt += src[STAT + 2 * KP];
+    for (int b = 0; b < NBLK; ++b)
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) h[b][q] += src[b * 256 + (sub + 4 * q) * 16 + c16];
-        if (lane < KP) { v += src[STAT + lane]; ssum += src[STAT + KP + lane]; }
-    }
+        for (int q = 0; q < 4; ++q) h[b][q] = src[b * 256 + (sub + 4 * q) * 16 + c16];
+    if (lane < KP) { v = src[STAT + lane]; ssum = src[STAT + KP + lane]; }
     acc_to_lds<NB>(h, s_H, lane);
     if (lane < KP) s_s[lane] = ssum;
     wave_sync();
