@@ -10,7 +10,7 @@
 // one per coordinate, whose byte offsets the order table holds per sweep position (34 dwords loaded into SGPRs at
 // the start of a sweep, indexed with s_movrels).  Inside block k everything is static — the Gram operand is the register holding G[u][k], the lane that
 // owns k is k % 16, and its (negated) increment reaches the row as the DPP row_newbcast:k%16 source operand of a
-// 64-bit v_fmac_f64 (gfx90a+ "DP ALU DPP").  Per step and wave (4 genes): 8 vector + 5 scalar instructions, no
+// 64-bit v_fmac_f64 (gfx90a+ "DP ALU DPP").  Per step and wave (4 genes): 7 vector + 5 scalar instructions, no
 // memory or LDS access; the sweep is one inline-asm block (the compiler turns a C++ switch into a compare tree with
 // register copies at the merge).  Without LDS the occupancy is set by registers alone (REG_WAVES(KMAX) waves per
 // SIMD), where the LDS-resident variant (insider_cd_row16.hpp) held 5 waves per CU at K = 30.
@@ -31,8 +31,8 @@ struct RegState {
 
 // ---- the sweep as one asm block -----------------------------------------------------------------------------------
 // Block for coordinate KK (slot s = KK / 16, owner lane it = KK % 16), src/coordinate_descent.cpp:91-110 in covariance
-// form: c = soft(h_s, la) * inv_s; dn = beta_s - c; beta_s[it] = c; h_u += bcast_it(dn) * G_u[KK].  soft(h, la) =
-// h - clamp(h, -la, la).  Screened-out coordinates and parked genes carry inv = beta = 0, i.e. a zero increment.
+// form: x = soft(h_s, la); dn = beta_s - x inv_s (one fma: minus the increment); beta_s[it] -= dn;
+// h_u += bcast_it(dn) * G_u[KK].  soft(h, la) = h - clamp(h, -la, la); x = 0 gives dn = beta_s and beta_s[it] = 0 exactly.  Screened-out coordinates and parked genes carry inv = beta = 0, i.e. a zero increment.
 // The sweep's 34 block offsets (positions 0..33; position K and beyond hold the exit block) are loaded into
 // s[64:97] at the start of the sweep and turned into the low words of the block addresses; the table of blocks
 // (REG_BLOCK bytes apart, placed with .org, which also asserts that no block outgrows its slot) starts on a 4 KiB
@@ -48,11 +48,10 @@ struct RegState {
     "v_max_f64 %[c], %[c], -%[la]\n"                             \
     "v_add_f64 %[c], %[" HS "], -%[c]\n"                         \
     "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
-    "v_mul_f64 %[c], %[c], %[" IS "]\n"                          \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
-    "v_mov_b64 %[" BS "], %[c]\n"                                \
-    "s_mov_b64 exec, %[ex]\n"                                    \
-    "s_add_u32 m0, m0, 1\n"
+    "s_add_u32 m0, m0, 1\n"                                      \
+    "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
+    "s_mov_b64 exec, %[ex]\n"
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
 #define REG_BLOCK2_LO(KK) \
     REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) "s_setpc_b64 vcc\n"

@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
             wave_sync();
             if (valid) {
                 double y = -s_H[(KP - 1) * KP + lane];     // - bc_r (the x slot is the last one of the padded row)
-                for (int b = 0; b < K; ++b) y += s_H[lane * KP + b] * s_s[b];
+                for (int b = 0; b < K; ++b) y += s_H[b * KP + lane] * s_s[b];   // H symmetric: conflict-free column walk
                 v += w * y;
             }
             const double w2 = w * w;
@@ -1061,7 +1061,7 @@ __global__ void __launch_bounds__(64) k_level_reduce(LevelReduceArgs a)
         double y = 0.0;
         if (valid) {
             y = a.SC[(size_t)(a.sc_off + l) * KP + lane] + v;
-            for (int b = 0; b < K; ++b) y -= a.CCt[lane * KP + b] * s_s[b];
+            for (int b = 0; b < K; ++b) y -= a.CCt[b * KP + lane] * s_s[b];      // CC' symmetric: coalesced
         }
         eq[KP * KP + lane] = y;
     }
