@@ -417,6 +417,35 @@ __device__ __forceinline__ bool chol_solve_lds(double *A, int KP, int K, double 
 }
 
 // ---------------------------------------------------------------------------------------------
+// wave-level solve of a symmetric positive definite system in REGISTERS (K <= KP <= 32): lane l holds row l of A
+// and b_l; Gauss-Jordan elimination without pivoting (on an SPD matrix the pivots are the d_j of L D L', all > 0,
+// and the elimination is as stable as Cholesky).  The pivot row reaches the other lanes through v_readlane into
+// SGPRs, which feed the fused multiply-adds directly; no LDS, no barriers, one reciprocal per column.
+// solve(XtX, Xty, likely_sympd) (src/optimize.cpp:175,190).  Returns false on a non-positive pivot.
+// ---------------------------------------------------------------------------------------------
+template <int KP>
+__device__ __forceinline__ bool gj_solve_regs(double (&row)[KP], int K, double &b, int lane)
+{
+    bool ok = true;
+    double diag = 1.0;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        if (j < K) {                                     // wave-uniform
+            const double piv = readlane_d(row[j], j);
+            ok = ok && piv > 0.0;
+            const double rp = 1.0 / piv;
+            const double f = lane == j ? 0.0 : row[j] * rp;
+            diag = lane == j ? piv : diag;
+#pragma unroll
+            for (int c = j + 1; c < KP; ++c) row[c] = fma(-f, readlane_d(row[c], j), row[c]);
+            b = fma(-f, readlane_d(b, j), b);
+        }
+    }
+    b /= diag;
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Kernel: complement statistics of every line from its held-out list (both sides of the path)
 // ---------------------------------------------------------------------------------------------
 // unit u, segment s of nseg: batch pairs [s * per, (s+1) * per) of line u's list.  Output: Geo<NB>::STAT doubles at
@@ -1102,19 +1131,32 @@ __global__ void __launch_bounds__(64) k_level_solve(const double *__restrict__ e
                                                     int *__restrict__ fail)
 {
     constexpr int KP = Geo<NB>::KP;
-    __shared__ double s_A[KP * KP];
     const int l = blockIdx.x, lane = threadIdx.x;
     if (l >= L) return;
     if (lvl_count[l] == 0) return;   // level without samples: the reference never visits it (:147)
     const double *src = eq + (size_t)l * (KP * KP + KP);
-    for (int i = lane; i < KP * KP; i += WAVE) s_A[i] = src[i];
-    wave_sync();
-    if (lane < K) s_A[lane * KP + lane] += lambda;                                      // :174,187
-    double b = lane < KP ? src[KP * KP + lane] : 0.0;
-    wave_sync();
-    const bool ok = chol_solve_lds(s_A, KP, K, b, lane);                                // :175,190
-    if (!ok) { if (lane == 0) *fail = 1; return; }
-    if (lane < K) Arows[(size_t)l * KP + lane] = b;
+    if constexpr (NB <= 2) {
+        // row `lane` of XtX in registers (the matrix is symmetric: column walks are coalesced)
+        double row[KP];
+#pragma unroll
+        for (int c = 0; c < KP; ++c) row[c] = lane < KP ? src[c * KP + lane] : 0.0;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) row[c] += (c == lane && lane < K) ? lambda : 0.0;      // :174,187
+        double b = lane < KP ? src[KP * KP + lane] : 0.0;
+        const bool ok = gj_solve_regs<KP>(row, K, b, lane);                                 // :175,190
+        if (!ok) { if (lane == 0) *fail = 1; return; }
+        if (lane < K) Arows[(size_t)l * KP + lane] = b;
+    } else {
+        __shared__ double s_A[KP * KP];
+        for (int i = lane; i < KP * KP; i += WAVE) s_A[i] = src[i];
+        wave_sync();
+        if (lane < K) s_A[lane * KP + lane] += lambda;                                      // :174,187
+        double b = lane < KP ? src[KP * KP + lane] : 0.0;
+        wave_sync();
+        const bool ok = chol_solve_lds(s_A, KP, K, b, lane);                                // :175,190
+        if (!ok) { if (lane == 0) *fail = 1; return; }
+        if (lane < K) Arows[(size_t)l * KP + lane] = b;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
