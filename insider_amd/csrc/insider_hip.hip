@@ -62,7 +62,6 @@ struct CovTables {   // per covariate, device
 };
 // continuous columns share one table: a single pseudo-level whose members are all samples, in 16-sample chunks
 
-constexpr int LEVEL_CHUNK = 4;   // member samples per wave of k_level_partial
 
 }  // namespace
 

@@ -30,6 +30,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int WAVE = 64;
 constexpr int CHUNK = 128;      // elements per streaming step (2 per lane); line pitches are multiples of it
 
+constexpr int LEVEL_CHUNK = 4;   // member samples per wave of k_level_partial (row update, stage 1)
 constexpr int ORDER_ROW = 320;   // bytes per sweep in the coordinate-order table (see k_order_table)
 
 constexpr int CODE_TRAIN = 1;   // bit 0 of a mask code: entry is in the train set
@@ -970,11 +971,10 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
     for (int b = 0; b < NBLK; ++b) hsum[b] = d4{0.0, 0.0, 0.0, 0.0};
     double v = 0.0, ssum = 0.0, w2sum = 0.0;
     // the statistics of member mi + 1 are loaded while member mi is processed
-    auto load_stat = [&](int mi, d4 (&h)[NBLK]) {
+    auto load_stat = [&](int r, d4 (&h)[NBLK]) {
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) h[b] = d4{0.0, 0.0, 0.0, 0.0};
         if (!a.masked) return;
-        const int r = a.members[mi];
         for (int sg = 0; sg < a.nseg; ++sg) {
             const double *src = a.stat + ((size_t)sg * a.n + r) * STAT;
 #pragma unroll
@@ -984,36 +984,50 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
         }
     };
     const int m_begin = a.chunk_begin[ch], m_end = a.chunk_end[ch];
+    const int nm = m_end - m_begin;                          // <= LEVEL_CHUNK
+    // the chunk's member ids, own rows and weights are fetched once (lane t < nm holds member t): the dependent
+    // chain members -> level id -> factor rows is paid per chunk, not per member
+    int r_l = 0, own_l = 0;
+    double w_l = 1.0;
+    if (lane < nm) {
+        r_l = a.members[m_begin + lane];
+        own_l = a.cov >= 0 ? a.lvl_off[a.cov] + a.lev[(size_t)a.cov * a.n + r_l] : a.own_row;
+        w_l = a.weights ? a.weights[r_l] : 1.0;
+    }
+    // s_r: everything but this covariate's own contribution (the Gauss-Seidel residual of :338,344 is x_r - s_r'C)
+    double s_all[LEVEL_CHUNK], w_all[LEVEL_CHUNK];
+#pragma unroll
+    for (int t = 0; t < LEVEL_CHUNK; ++t) {
+        const int r = __builtin_amdgcn_readlane(r_l, t), own = __builtin_amdgcn_readlane(own_l, t);
+        w_all[t] = readlane_d(w_l, t);
+        s_all[t] = (valid && t < nm) ? a.R[(size_t)r * KP + lane] - w_all[t] * a.Astack[(size_t)own * KP + lane] : 0.0;
+    }
     d4 hn[NBLK];
-    load_stat(m_begin, hn);
-    for (int mi = m_begin; mi < m_end; ++mi) {
-        const int r = a.members[mi];
-        const double w = a.weights ? a.weights[r] : 1.0;
-        // s_r: everything but this covariate's own contribution (the Gauss-Seidel residual of :338,344 is x_r - s_r'C)
-        double s = 0.0;
-        if (valid) {
-            const int own = a.cov >= 0 ? a.lvl_off[a.cov] + a.lev[(size_t)a.cov * a.n + r] : a.own_row;
-            s = a.R[(size_t)r * KP + lane] - w * a.Astack[(size_t)own * KP + lane];
-        }
-        ssum += w * s;
-        w2sum += w * w;
-        if (a.masked) {
-            d4 h[NBLK];
+    load_stat(__builtin_amdgcn_readlane(r_l, 0), hn);
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) h[b] = hn[b];
-            load_stat(mi + 1 < m_end ? mi + 1 : mi, hn);
-            wave_sync();
-            acc_to_lds<NB>(h, s_H, lane);
-            if (lane < KP) s_s[lane] = valid ? s : 0.0;
-            wave_sync();
-            if (valid) {
-                double y = -s_H[(KP - 1) * KP + lane];     // - bc_r (the x slot is the last one of the padded row)
-                for (int b = 0; b < K; ++b) y += s_H[b * KP + lane] * s_s[b];   // H symmetric: conflict-free column walk
-                v += w * y;
+    for (int t = 0; t < LEVEL_CHUNK; ++t) {
+        if (t < nm) {                                        // wave-uniform
+            const double w = w_all[t], s = s_all[t];
+            ssum += w * s;
+            w2sum += w * w;
+            if (a.masked) {
+                d4 h[NBLK];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) h[b] = hn[b];
+                load_stat(__builtin_amdgcn_readlane(r_l, t + 1 < nm ? t + 1 : t), hn);
+                wave_sync();
+                acc_to_lds<NB>(h, s_H, lane);
+                if (lane < KP) s_s[lane] = s;
+                wave_sync();
+                if (valid) {
+                    double y = -s_H[(KP - 1) * KP + lane];     // - bc_r (the x slot is the last one of the padded row)
+                    for (int b = 0; b < K; ++b) y += s_H[b * KP + lane] * s_s[b];   // H symmetric: conflict-free column walk
+                    v += w * y;
+                }
+                const double w2 = w * w;
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) hsum[b] += w2 * h[b];
             }
-            const double w2 = w * w;
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) hsum[b] += w2 * h[b];
         }
     }
     double *out = a.part + (size_t)ch * (STAT + 2 * KP + 2);

@@ -129,6 +129,42 @@ def test_strong_cd_matches_oracle(oracle, K, lam, alpha, tol):
         assert same_sweeps >= B - 2
 
 
+@pytest.mark.parametrize("K", [2, 3, 8, 15, 16] + list(range(17, 33)))
+def test_strong_cd_every_register_kernel_instantiation(oracle, K):
+    """K <= 32 runs the register-resident kernel, instantiated per even K above 16 (insider_cd_reg.hpp): every
+    instantiation against the oracle, with screened-out coordinates (strong rule) and a partial last wave."""
+    rng = np.random.default_rng(100 + K)
+    B, m = 7, 120
+    Xs = rng.standard_normal((B, m, K)) @ (np.eye(K) + 0.3 * rng.standard_normal((K, K)))
+    bt = rng.standard_normal((B, K)) * (rng.random((B, K)) < 0.5)
+    ys = np.einsum("bmk,bk->bm", Xs, bt) + 0.3 * rng.standard_normal((B, m))
+    Gs = np.einsum("bmk,bml->bkl", Xs, Xs)
+    qs = np.einsum("bmk,bm->bk", Xs, ys)
+    ws = 0.1 * rng.standard_normal((B, K))
+    lam = 0.35 * float(np.max(np.abs(qs)))       # the strong rule screens out part of the coordinates
+    beta, sw = api.strong_coordinate_descent(None, None, ws, lam, 0.6, Gs, qs, tol=1e-10, seed=5, it=3,
+                                             return_sweeps=True)
+    for b in range(B):
+        ob, osw = oracle.strong_cd(Xs[b], ys[b], ws[b], lam, 0.6, Gs[b], qs[b], tol=1e-10, seed=5, unit=b, it=3)
+        assert abs(osw - sw[b]) <= 1, (K, b, osw, sw[b])
+        # one sweep of slack in the stopping rule (see test_strong_cd_matches_oracle) moves beta by ~sqrt(tol)
+        assert np.max(np.abs(ob - beta[b])) < (1e-8 if osw == sw[b] else 50 * np.sqrt(1e-10)), (K, b)
+        assert np.array_equal(ob == 0, beta[b] == 0)          # identical sparsity pattern
+
+
+@pytest.mark.parametrize("K", [17, 19, 22, 25, 28, 31])
+def test_optimize_column_kernel_instantiations(oracle, K):
+    w = workloads.small(K=K, n=90, p=75, seed=K, f=0.2)
+    A, C = _cp(w)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize(A, C, w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=1, seed=3)
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          tuning=1, max_iter=1, seed=3)
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-8
+    assert got["loss"] == pytest.approx(ref["loss"], rel=1e-9)
+
+
 def test_strong_cd_hand_kat():
     # SURVEY.md 8c item 4
     beta = api.strong_coordinate_descent(None, None, np.zeros(1), 1.0, 0.5, np.array([[2.0]]), np.array([4.0]),
