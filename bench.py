@@ -65,7 +65,7 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter):
     from insider_amd import workloads
     from oracle import c_oracle
     cn, cp = workloads.CONFIGS[name][0], workloads.CONFIGS[name][1]
-    genes = 16
+    genes = 3 * min(30, n_cores)      # ~10-15 s of CPU work: three waves of the column step's threads
     w = workloads.make(name, gene_range=(0, genes))
     row_t, col_t = min(10, n_cores), min(30, n_cores)      # the reference's hard-coded 10 / 30 (src/optimize.cpp:140,376)
     t0 = time.perf_counter()
