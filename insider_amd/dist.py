@@ -110,13 +110,41 @@ class DeviceAllreduce:
         self.calls.append(count)
 
 
-def attach(ds, gene_offset, rank, world, device=None, group=None, force=False):
+class StagedHostAllreduce:
+    """All-reduce of a DEVICE buffer through the HOST: wait for the library's stream, copy the buffer to pinned-size host
+    memory, all-reduce it with a CPU backend (gloo), copy it back.  Slow by construction; it exists so that the sharded
+    HIP path (per-level equations and loss terms crossing ranks between kernels) can be run with several processes
+    on ONE GPU, where RCCL refuses duplicate devices (tests/test_gpu_sharded.py)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.calls = []
+
+    def __call__(self, ptr, count, stream=0):
+        import torch
+        if self.hip.hipStreamSynchronize(stream) != 0:
+            raise RuntimeError("hipStreamSynchronize failed")
+        host = np.empty(count, dtype=np.float64)
+        if self.hip.hipMemcpy(host.ctypes.data, ptr, count * 8, 2) != 0:      # hipMemcpyDeviceToHost
+            raise RuntimeError("hipMemcpy D2H failed")
+        self.dist.all_reduce(torch.from_numpy(host), op=self.dist.ReduceOp.SUM, group=self.group)
+        if self.hip.hipMemcpy(ptr, host.ctypes.data, count * 8, 1) != 0:      # hipMemcpyHostToDevice
+            raise RuntimeError("hipMemcpy H2D failed")
+        self.calls.append(count)
+
+
+def attach(ds, gene_offset, rank, world, device=None, group=None, force=False, staged=False):
     """Mark an InsiderData handle as one gene slab of a `world`-rank job and install the RCCL all-reduce.
-    ``force``: install (and call) the all-reduce even for world == 1 (plumbing rehearsal on a single GPU)."""
+    ``force``: install (and call) the all-reduce even for world == 1 (plumbing rehearsal on a single GPU).
+    ``staged``: all-reduce through the host with the process group's CPU backend (several ranks on one GPU)."""
     if world <= 1 and not force:
         ds.set_shard(gene_offset, 0, 1, None)
         return None
-    ar = DeviceAllreduce(device if device is not None else 0, group)
+    ar = StagedHostAllreduce(group) if staged else DeviceAllreduce(device if device is not None else 0, group)
     ds.set_shard(gene_offset, rank, world, ar)
     if force:
         ds.set_option("force_allreduce", 1)

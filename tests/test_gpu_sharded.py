@@ -1,0 +1,82 @@
+"""The gene-sharded HIP path with TWO processes on ONE GPU: each rank holds a gene slab on cuda:0,
+the per-level normal equations and the loss terms cross ranks between kernels through the all-reduce callback of the
+C ABI — here a host-staged gloo all-reduce (RCCL refuses two ranks on one device; on a multi-GPU node the same callback
+slot carries the stream-ordered RCCL all-reduce of insider_amd/dist.py).  The sharded fit must reproduce the
+single-process fit: row factors, the gathered gene factors and the loss trajectory, to summation-order tolerance.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from insider_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+CASE = dict(n=120, p=150, level_counts=(7, 4), K=9, f=0.15, seed=23, with_na=True)
+ITERS = 12
+
+
+def _fit(rank, world, staged):
+    from insider_amd import api, dist as idist
+    w = workloads.small(**CASE)
+    lo, hi = idist.shard_range(w.p, rank, world)
+    ds = api.InsiderData(w.X[:, lo:hi], w.levels, w.M_train[:, lo:hi], w.M_test[:, lo:hi])
+    ar = idist.attach(ds, lo, rank, world, staged=staged)
+    A = [a.copy(order="F") for a in w.A0]
+    C = w.C0[:, lo:hi].copy(order="F")
+    res = ds.optimize(A, C, w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=ITERS, global_tol=-1.0, seed=5)
+    ds.close()
+    return dict(A=[np.array(a) for a in res["row_matrices"].values()], C=res["column_factor"], traj=res["traj"],
+                loss=res["loss"], test_rmse=res["test_rmse"], lo=lo, hi=hi, calls=len(ar.calls) if ar else 0)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _fit(rank, world, staged=True)))
+    except Exception as e:   # surface the failure in the parent instead of a hang
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_rank():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert isinstance(out[r], dict), out[r]
+    single = _fit(0, 1, staged=False)
+
+    # one all-reduce per covariate per outer iteration + one per loss checkpoint (initial fit, iterations 0 and 10)
+    n_cov = len(CASE["level_counts"])
+    assert out[0]["calls"] == out[1]["calls"] == n_cov * (ITERS + 1) + 3
+
+    def relerr(a, b):
+        return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+    for i in range(n_cov):                                   # row factors: replicated, bit-identical across ranks
+        assert np.array_equal(out[0]["A"][i], out[1]["A"][i])
+        assert relerr(out[0]["A"][i], single["A"][i]) < 1e-9
+    C = np.concatenate([out[0]["C"], out[1]["C"]], axis=1)    # gene factors: gathered slabs
+    assert out[0]["hi"] == out[1]["lo"] and C.shape == single["C"].shape
+    assert relerr(C, single["C"]) < 1e-9
+    assert np.allclose(out[0]["traj"], out[1]["traj"], rtol=0, atol=0, equal_nan=True)
+    np.testing.assert_allclose(out[0]["traj"][:, 1:8], single["traj"][:, 1:8], rtol=1e-10)
+    assert out[0]["loss"] == pytest.approx(single["loss"], rel=1e-11)
+    assert out[0]["test_rmse"] == pytest.approx(single["test_rmse"], rel=1e-11)
