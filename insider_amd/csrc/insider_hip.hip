@@ -103,6 +103,11 @@ struct insider_hip_handle {
     int order_rows = 0;
     // gene scheduling for the CD kernel: genes sorted by the sweep count of their previous solve
     int *gene_ids = nullptr, *gene_perm = nullptr, *sweeps_sorted = nullptr;
+    // longest-first gene orders of outer iterations 0..2 of the previous optimize() on this handle: the early iterations
+    // of the next call (tune()'s next grid point) have similar per-gene sweep counts, its later ones do not
+    static constexpr int EARLY = 3;
+    int *perm_early[EARLY] = {nullptr, nullptr, nullptr};
+    bool have_early[EARLY] = {false, false, false};
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     bool have_perm = false;
@@ -136,6 +141,11 @@ void free_workspace(insider_hip_handle *h)
     h->order_rows = 0;
     for (void *q : {(void *)h->gene_ids, (void *)h->gene_perm, (void *)h->sweeps_sorted, h->sort_tmp}) if (q) (void)hipFree(q);
     h->gene_ids = h->gene_perm = h->sweeps_sorted = nullptr;
+    for (int e = 0; e < insider_hip_handle::EARLY; ++e) {
+        if (h->perm_early[e]) (void)hipFree(h->perm_early[e]);
+        h->perm_early[e] = nullptr;
+        h->have_early[e] = false;
+    }
     h->sort_tmp = nullptr;
     h->sort_tmp_bytes = 0;
     h->have_perm = false;
@@ -191,6 +201,8 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->gene_ids, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sweeps_sorted, (size_t)h->p))) return rc;
+    for (int e = 0; e < insider_hip_handle::EARLY; ++e)
+        if ((rc = dmalloc(&h->perm_early[e], (size_t)h->p))) return rc;
     {
         std::vector<int> ids(h->p);
         for (int64_t i = 0; i < h->p; ++i) ids[i] = (int)i;
@@ -320,8 +332,9 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
 
 // column update from the statistics: elastic-net CD (alpha > 0) or ridge (alpha == 0), or evaluation only
 int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambda, double alpha, double tol,
-                     int checkpoint, bool timed)
+                     int checkpoint, bool timed, int outer_iter = -1)
 {
+    const bool early = outer_iter >= 0 && outer_iter < insider_hip_handle::EARLY;
     const int NBLK = h->NB * (h->NB + 1) / 2, STAT = NBLK * 256;
     Timer t;
     int rc = t.begin(h, timed);
@@ -376,7 +389,9 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.test_from_stats = masked && h->no_na;
         a.sweeps = h->sweeps;
         a.sweep_bins = (timed && solve) ? h->sweep_total : nullptr;
-        a.gene_perm = (solve && h->have_perm) ? h->gene_perm : nullptr;
+        a.gene_perm = !solve ? nullptr : (early && h->have_early[outer_iter]) ? h->perm_early[outer_iter]
+                                       : h->have_perm                         ? h->gene_perm
+                                                                              : nullptr;
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
         if (h->cd_variant == 0 && h->K <= 32) {
             REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a));
@@ -396,6 +411,11 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweeps, h->sweeps_sorted,
                                                               h->gene_ids, h->gene_perm, (int)h->p, 0, 32, h->stream));
         h->have_perm = true;
+        if (early) {
+            HIPCHECK(hipMemcpyAsync(h->perm_early[outer_iter], h->gene_perm, (size_t)h->p * sizeof(int),
+                                    hipMemcpyDeviceToDevice, h->stream));
+            h->have_early[outer_iter] = true;
+        }
     }
     return INSIDER_OK;
 }
@@ -989,7 +1009,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         if (alpha != 0.0)
             if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
         if (masked) if ((rc = launch_col_stats(h, true))) return rc;
-        if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true))) return rc;  // :376
+        if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true, (int)iter))) return rc;  // :376
         if (checkpoint) {                                                                       // :381-408
             if ((rc = launch_test_sse(h, masked, true))) return rc;
             pre_loss = loss;
