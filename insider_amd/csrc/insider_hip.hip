@@ -359,7 +359,11 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.sse_test = h->sse_test;
         a.test_from_stats = masked && h->no_na;
         a.fail = h->failflag;
-        hipLaunchKernelGGL((k_ridge_cols<1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
+        if (h->K <= 32 && h->cd_variant == 0) {
+            REG_DISPATCH(h->K, hipLaunchKernelGGL((k_ridge_cols_reg<SL_, KM_>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a));
+        } else {
+            hipLaunchKernelGGL((k_ridge_cols<1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
+        }
         KCHECK();
         if (solve) HIPCHECK(hipMemsetAsync(h->sweeps, 0, (size_t)h->p * sizeof(int), h->stream));
     } else {

@@ -1377,3 +1377,4 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
 
 #include "insider_cd_row16.hpp"
 #include "insider_cd_reg.hpp"
+#include "insider_ridge_reg.hpp"

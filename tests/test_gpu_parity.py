@@ -165,6 +165,20 @@ def test_optimize_column_kernel_instantiations(oracle, K):
     assert got["loss"] == pytest.approx(ref["loss"], rel=1e-9)
 
 
+@pytest.mark.parametrize("K", [3, 16, 17, 20, 24, 27, 31, 32])
+@pytest.mark.parametrize("tuning", [1, 0])
+def test_ridge_column_kernel_instantiations(oracle, K, tuning):
+    """alpha == 0: the register-resident Gauss-Jordan ridge solve (insider_ridge_reg.hpp), every slot geometry."""
+    w = workloads.small(K=K, n=100, p=70, seed=K + 50, f=0.2, with_na=(K % 2 == 0))
+    A, C = _rand_factors(w, K)
+    M = w.M_train if tuning == 1 else np.ones_like(w.M_train)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize_col(A, C.copy(order="F"), lambda_=0.7, alpha=0.0, tuning=tuning)
+    ds.close()
+    ref, _ = oracle.optimize_col(w.X, M, _R(w, A), C, 0.7, 0.0, tuning=tuning)
+    assert relerr(got, ref) < 1e-10, relerr(got, ref)
+
+
 def test_strong_cd_hand_kat():
     # SURVEY.md 8c item 4
     beta = api.strong_coordinate_descent(None, None, np.zeros(1), 1.0, 0.5, np.array([[2.0]]), np.array([4.0]),
