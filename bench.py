@@ -174,7 +174,11 @@ def main():
                          "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],
                          "fp64_tflops": fl / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
                          "fp64_frac": fl / (gram_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gram_ms > 0 else 0.0,
-                         "row_side_avg_launch_ms": prof["row_stats_ms"] / max(prof["row_stats_launches"], 1)},
+                         "row_side_avg_launch_ms": prof["row_stats_ms"] / max(prof["row_stats_launches"], 1),
+                         # what actually binds it: 3 (K <= 31) v_mfma_f64_16x16x4 per 4 held-out entries, 2048 flop each
+                         "binding": "mfma-f64 (HBM traffic is 0.23x the algorithmic bytes: the kernel reads held-out lists)",
+                         "mfma_f64_executed_frac": (f * n * p_loc / 4.0) * (3 if K <= 31 else 0) * 2048.0 /
+                                                   (gram_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gram_ms > 0 and K <= 31 and K >= 16 else None},
             "cd_kernel": {"kernel": "k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)",
                           "avg_launch_ms": prof["cd_ms"] / max(prof["cd_launches"], 1),
                           "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,
