@@ -59,6 +59,15 @@ int dmalloc(T **p, size_t count)
 struct CovTables {   // per covariate, device
     int L = 0, nchunks = 0;
     int *chunk_level = nullptr, *chunk_begin = nullptr, *chunk_end = nullptr, *lvl_chunk_ptr = nullptr;
+    // merged masked row update (insider_row_merged.hpp), built once per data set
+    uint32_t *grp = nullptr;          // [p][L + 1] positions of the level groups inside each gene's sorted held-out samples
+    uint16_t *slev = nullptr;         // per entry of every gene's level-grouped held-out samples: stacked level of each other covariate
+    uint32_t *item_begin = nullptr, *item_end = nullptr;   // weighted-SYRK work items: ranges of the (gene, count) lists
+    int *lvl_item_ptr = nullptr;      // [L + 1] items of every level
+    int nitems = 0;
+    int *wl_idx = nullptr;            // (gene, count) lists of every level, padded like the held-out lists
+    double *wl_w = nullptr;
+    double *paircnt = nullptr;        // [L][SLcat] samples in (level of this covariate, stacked level of another one)
 };
 // continuous columns share one table: a single pseudo-level whose members are all samples, in 16-sample chunks
 
@@ -96,6 +105,11 @@ struct insider_hip_handle {
     double *Astack = nullptr, *R = nullptr, *C = nullptr, *RtR = nullptr, *CCt = nullptr, *Qfull = nullptr, *SC = nullptr;
     double *stat = nullptr, *stat_col = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
     double *lvl_sum = nullptr;
+    double *Strain = nullptr;         // per-level sums of X over TRAIN entries (p x SLP), once per data set
+    double *U = nullptr, *Ylvl = nullptr, *wpart = nullptr, *Vlev = nullptr;   // merged row update workspace
+    int max_items = 0;
+    bool merged = false;              // the merged masked row update is available (categorical covariates only)
+    int row_merged = 1;               // option: use it
     double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
     int *sweeps = nullptr, *failflag = nullptr;
     unsigned long long *sweep_total = nullptr;
@@ -130,7 +144,7 @@ namespace {
 void free_workspace(insider_hip_handle *h)
 {
     double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
-                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
+                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->sweeps) (void)hipFree(h->sweeps);
@@ -187,6 +201,13 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->sc_part, (size_t)h->sc_blocks * h->SL * KP))) return rc;
     if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP + 2)))) return rc;
     if ((rc = dmalloc(&h->lvl_sum, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2)))) return rc;
+    if (h->merged) {
+        const int LP = (int)round_up(std::max(h->max_L, 1), 2);
+        if ((rc = dmalloc(&h->U, (size_t)h->p * LP))) return rc;
+        if ((rc = dmalloc(&h->Ylvl, (size_t)std::max(h->max_L, 1) * KP))) return rc;
+        if ((rc = dmalloc(&h->wpart, (size_t)std::max(h->max_items, 1) * STAT))) return rc;
+        if ((rc = dmalloc(&h->Vlev, (size_t)h->p * h->SLP))) return rc;
+    }
     if ((rc = dmalloc(&h->eq, (size_t)h->max_L * (KP * KP + KP)))) return rc;
     if ((rc = dmalloc(&h->sse_train, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sse_test, (size_t)h->p))) return rc;
@@ -442,6 +463,9 @@ int launch_test_sse(insider_hip_handle *h, int masked, bool timed)
     return t.end(h, h->ev_test);
 }
 
+// masked update without per-sample statistics (insider_row_merged.hpp)?
+bool use_merged(const insider_hip_handle *h, int masked) { return masked && h->merged && h->row_merged && h->m == 0; }
+
 int launch_row_stats(insider_hip_handle *h, bool timed)
 {
     Timer t;
@@ -494,14 +518,49 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
     ra.SC = h->SC;
     ra.sc_off = row0;
     ra.eq = h->eq;
-    NB_DISPATCH(h->NB, {
-        (void)WPB_;
-        constexpr int PLEN = Geo<NB_>::STAT + 2 * Geo<NB_>::KP + 2;
-        hipLaunchKernelGGL((k_level_partial<NB_>), dim3(ct.nchunks), dim3(64), 0, h->stream, la);
-        hipLaunchKernelGGL(k_level_sum, dim3(cdiv(PLEN, 16), ct.L), dim3(256), 0, h->stream, (const double *)h->lvl_part,
-                           (const int *)ct.lvl_chunk_ptr, PLEN, h->lvl_sum);
-        hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(ct.L), dim3(64), 0, h->stream, ra);
-    });
+    if (!cont && use_merged(h, masked)) {
+        // merged update: one weighted rank-one term per (level, gene) pair, one look-up per held-out entry
+        const int L = ct.L, LP = (int)round_up(L, 2), KP = h->KP;
+        hipLaunchKernelGGL(k_gene_v, dim3(cdiv(h->p, 64), cdiv(h->SLP, 64)), dim3(256), 0, h->stream, (const double *)h->C,
+                           (const double *)h->Astack, (int)h->p, h->SLcat, h->SLP, h->K, KP, h->Vlev);
+        hipLaunchKernelGGL((k_gene_u<4>), dim3(cdiv(h->p, 4)), dim3(256), (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double),
+                           h->stream, (const uint32_t *)ct.grp, (const uint16_t *)ct.slev,
+                           (size_t)h->col_entries + LIST_BLOCK, h->c - 1, L, LP, (const double *)h->Vlev, h->SLP, (int)h->p,
+                           h->SLcat, h->U);
+        KCHECK();
+        {   // Y = U'C, the same reduction over genes as (S C')
+            const int LT = 256 / KP;
+            dim3 grid(h->sc_blocks, cdiv(L, LT));
+            hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream, (const double *)h->U, L, LP,
+                               (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
+            hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(L * KP, 16)), dim3(256), 0, h->stream,
+                               (const double *)h->sc_part, h->sc_blocks, L * KP, h->Ylvl);
+            KCHECK();
+        }
+        NB_DISPATCH(h->NB, {
+            constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
+            if (ct.nitems > 0)   // no held-out entry at all: every level sum is zero
+            hipLaunchKernelGGL((k_wsyrk<NB_, WPB_>), dim3(cdiv(ct.nitems, WPB_)), dim3(WPB_ * 64), 0, h->stream,
+                               (const uint32_t *)ct.item_begin, (const uint32_t *)ct.item_end, ct.nitems,
+                               (const int *)ct.wl_idx, (const double *)ct.wl_w, (const double *)h->C, (int64_t)h->p,
+                               h->wpart);
+            hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), L), dim3(256), 0, h->stream, (const double *)h->wpart,
+                               (const int *)ct.lvl_item_ptr, STAT_, h->lvl_sum, PLEN);
+            hipLaunchKernelGGL(k_level_pack, dim3(L), dim3(64), 0, h->stream, (const double *)h->Ylvl,
+                               (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
+                               (const int *)(h->lvl_count_all + h->lvl_off[i]), L, h->K, KP, STAT_, h->lvl_sum);
+            hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(L), dim3(64), 0, h->stream, ra);
+        });
+    } else {
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            constexpr int PLEN = Geo<NB_>::STAT + 2 * Geo<NB_>::KP + 2;
+            hipLaunchKernelGGL((k_level_partial<NB_>), dim3(ct.nchunks), dim3(64), 0, h->stream, la);
+            hipLaunchKernelGGL(k_level_sum, dim3(cdiv(PLEN, 16), ct.L), dim3(256), 0, h->stream,
+                               (const double *)h->lvl_part, (const int *)ct.lvl_chunk_ptr, PLEN, h->lvl_sum, PLEN);
+            hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(ct.L), dim3(64), 0, h->stream, ra);
+        });
+    }
     KCHECK();
     int rc = do_allreduce(h, h->eq, (int64_t)ct.L * (h->KP * h->KP + h->KP));
     if (rc) return rc;
@@ -631,13 +690,15 @@ int download_factors(insider_hip_handle *h, double *const *A, double *C, int K)
 }
 
 // C C' and S_i C' for the row step (src/optimize.cpp:332 and the unmasked part of :166,188)
-int launch_row_prep(insider_hip_handle *h)
+int launch_row_prep(insider_hip_handle *h, int masked)
 {
     int rc = launch_gram(h, h->C, h->p, h->CCt);
     if (rc) return rc;
     const int KP = h->KP, LT = 256 / KP;
     dim3 grid(h->sc_blocks, cdiv(h->SL, LT));
-    hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream, (const double *)h->S, h->SL, h->SLP,
+    // the merged update wants (S^train C'): the per-level sums of the TRAIN entries, i.e. (S C') minus sum_r bc_r
+    hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream,
+                       (const double *)(use_merged(h, masked) ? h->Strain : h->S), h->SL, h->SLP,
                        (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
     KCHECK();
     const int len = h->SL * KP;
@@ -697,7 +758,11 @@ void insider_hip_destroy(insider_hip_handle *h)
         if (ct.chunk_begin) (void)hipFree(ct.chunk_begin);
         if (ct.chunk_end) (void)hipFree(ct.chunk_end);
         if (ct.lvl_chunk_ptr) (void)hipFree(ct.lvl_chunk_ptr);
+        for (void *q : {(void *)ct.grp, (void *)ct.slev, (void *)ct.item_begin, (void *)ct.item_end, (void *)ct.lvl_item_ptr,
+                        (void *)ct.wl_idx, (void *)ct.wl_w, (void *)ct.paircnt})
+            if (q) (void)hipFree(q);
     }
+    if (h->Strain) (void)hipFree(h->Strain);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -871,8 +936,16 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
         hipLaunchKernelGGL(k_line_sumsq, dim3(cdiv(p, 4)), dim3(256), 0, h->stream, (const double *)h->X,
                            (const uint8_t *)h->codes, h->ldn, (int)n, (int)p, h->yy_train, h->yy_all, cnt);
         hipLaunchKernelGGL(k_level_sums, dim3(cdiv(p * h->SLcat, 256)), dim3(256), 0, h->stream, (const double *)h->X,
-                           h->ldn, (int)p, (const int *)h->members_all, (const int *)h->lvl_ptr_all,
-                           (const int *)h->lvl_off_d, c, (int)n, h->SLcat, h->SLP, h->S);
+                           (const uint8_t *)nullptr, h->ldn, (int)p, (const int *)h->members_all,
+                           (const int *)h->lvl_ptr_all, (const int *)h->lvl_off_d, c, (int)n, h->SLcat, h->SLP, h->S);
+        if (m == 0) {   // train-only sums for the merged masked row update (categorical covariates only)
+            CR(dmalloc(&h->Strain, (size_t)p * h->SLP));
+            CH(hipMemsetAsync(h->Strain, 0, (size_t)p * h->SLP * sizeof(double), h->stream));
+            hipLaunchKernelGGL(k_level_sums, dim3(cdiv(p * h->SLcat, 256)), dim3(256), 0, h->stream, (const double *)h->X,
+                               (const uint8_t *)h->codes, h->ldn, (int)p, (const int *)h->members_all,
+                               (const int *)h->lvl_ptr_all, (const int *)h->lvl_off_d, c, (int)n, h->SLcat, h->SLP,
+                               h->Strain);
+        }
         if (m > 0)
             hipLaunchKernelGGL(k_cont_sums, dim3(cdiv(p * m, 256)), dim3(256), 0, h->stream, (const double *)h->X, h->ldn,
                                (int)p, (const double *)h->Zc, m, (int)n, h->SLcat, h->SLP, h->S);
@@ -921,6 +994,73 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
         CH(hipGetLastError());
         CH(hipStreamSynchronize(h->stream));
     }
+    // ---- merged masked row update: per covariate, the genes' held-out samples grouped by level, the (gene, count)
+    // lists of every level and the level-pair sample counts (insider_row_merged.hpp) -------------------------------------
+    if (m == 0) {
+        constexpr uint32_t SEG = 2048;   // list entries per weighted-SYRK work item (multiple of LIST_ALIGN)
+        std::vector<int> lev0((size_t)c * n);
+        CH(hipMemcpy(lev0.data(), h->lev, lev0.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < c; ++i) {
+            CovTables &ct = h->cov[i];
+            const int L = ct.L;
+            CR(dmalloc(&ct.grp, (size_t)p * (L + 1)));
+            const size_t plane = (size_t)h->col_entries + LIST_BLOCK;
+            if (h->SLcat > 65535) { insider_hip_destroy(h); return fail(INSIDER_ERR_UNSUPPORTED, "more than 65535 levels in total"); }
+            CR(dmalloc(&ct.slev, plane * (size_t)std::max(c - 1, 1)));
+            const size_t lds = (size_t)4 * L * sizeof(int);
+            if (lds > 60 * 1024) { insider_hip_destroy(h); return fail(INSIDER_ERR_UNSUPPORTED, "a covariate has more than 3840 levels"); }
+            hipLaunchKernelGGL(k_group_count, dim3(cdiv(p, 4)), dim3(256), lds, h->stream, (const uint32_t *)h->col_ptr,
+                               (const int *)h->col_idx, (const int *)(h->lev + (size_t)i * n), L, (int)p, ct.grp);
+            hipLaunchKernelGGL(k_group_fill, dim3(cdiv(p, 4)), dim3(256), lds, h->stream, (const uint32_t *)h->col_ptr,
+                               (const int *)h->col_idx, (const int *)h->lev, (const int *)h->lvl_off_d, c, (int)n, i, L,
+                               (int)p, (const uint32_t *)ct.grp, ct.slev, plane);
+            CH(hipGetLastError());
+            std::vector<uint32_t> grp((size_t)p * (L + 1));
+            CH(hipMemcpyAsync(grp.data(), ct.grp, grp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            CH(hipStreamSynchronize(h->stream));
+            // (gene, count) list of every level, padded to LIST_ALIGN; work items of at most SEG entries
+            std::vector<int> widx, lip(L + 1, 0);
+            std::vector<double> ww;
+            std::vector<uint32_t> ib, ie;
+            for (int l = 0; l < L; ++l) {
+                lip[l] = (int)ib.size();
+                const size_t start = widx.size();
+                for (int64_t j = 0; j < p; ++j) {
+                    const uint32_t cnt = grp[(size_t)j * (L + 1) + l + 1] - grp[(size_t)j * (L + 1) + l];
+                    if (cnt) { widx.push_back((int)j); ww.push_back((double)cnt); }
+                }
+                while ((widx.size() - start) % LIST_ALIGN) { widx.push_back(LIST_PAD); ww.push_back(0.0); }
+                for (size_t b = start; b < widx.size(); b += SEG) {
+                    ib.push_back((uint32_t)b);
+                    ie.push_back((uint32_t)std::min(b + SEG, widx.size()));
+                }
+            }
+            lip[L] = (int)ib.size();
+            if (widx.size() >= (1ull << 32)) { insider_hip_destroy(h); return fail(INSIDER_ERR_UNSUPPORTED, "level lists too long"); }
+            ct.nitems = (int)ib.size();
+            h->max_items = std::max(h->max_items, ct.nitems);
+            CR(dmalloc(&ct.wl_idx, widx.size() + LIST_BLOCK));
+            CR(dmalloc(&ct.wl_w, ww.size() + LIST_BLOCK));
+            CR(dmalloc(&ct.item_begin, ib.size() + 1));
+            CR(dmalloc(&ct.item_end, ie.size() + 1));
+            CR(dmalloc(&ct.lvl_item_ptr, lip.size()));
+            CH(hipMemcpy(ct.wl_idx, widx.data(), widx.size() * sizeof(int), hipMemcpyHostToDevice));
+            CH(hipMemcpy(ct.wl_w, ww.data(), ww.size() * sizeof(double), hipMemcpyHostToDevice));
+            CH(hipMemcpy(ct.item_begin, ib.data(), ib.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            CH(hipMemcpy(ct.item_end, ie.data(), ie.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            CH(hipMemcpy(ct.lvl_item_ptr, lip.data(), lip.size() * sizeof(int), hipMemcpyHostToDevice));
+            // samples per (level of covariate i, stacked level of another covariate): sum_{r in l} s_r = paircnt A
+            std::vector<double> pc((size_t)L * h->SLcat, 0.0);
+            for (int64_t r = 0; r < n; ++r) {
+                const int l = lev0[(size_t)i * n + r];
+                for (int q = 0; q < c; ++q)
+                    if (q != i) pc[(size_t)l * h->SLcat + h->lvl_off[q] + lev0[(size_t)q * n + r]] += 1.0;
+            }
+            CR(dmalloc(&ct.paircnt, pc.size()));
+            CH(hipMemcpy(ct.paircnt, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        h->merged = true;
+    }
     // the transposed copies were only needed to build the row-side lists
     (void)hipFree(h->Xt);
     (void)hipFree(h->codes_t);
@@ -954,6 +1094,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
     else if (s == "force_allreduce") h->force_allreduce = (int)value;   // call the all-reduce callback even when world == 1
+    else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update (default), 0 = per-sample statistics
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
@@ -1000,8 +1141,8 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     while (iter <= max_iter) {                                                                  // :325
         if (h->verbose && iter % 10 == 0) printf("Iteration %u ---------------------------------\n", iter);
         // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
-        if ((rc = launch_row_prep(h))) return rc;                                               // :332
-        if (masked) if ((rc = launch_row_stats(h, true))) return rc;
+        if ((rc = launch_row_prep(h, masked))) return rc;                                       // :332
+        if (masked && !use_merged(h, masked)) if ((rc = launch_row_stats(h, true))) return rc;
         for (int i = 0; i < h->c; ++i)
             if ((rc = row_update(h, i, -1, masked, lambda1))) return rc;                        // :339
         if (inc_continuous)
@@ -1106,8 +1247,8 @@ int insider_hip_optimize_row(insider_hip_handle *h, double *const *A, const doub
     HIPCHECK(hipSetDevice(h->device));
     if ((rc = ensure_workspace(h, K))) return rc;
     if ((rc = upload_factors(h, A, C, K))) return rc;
-    if ((rc = launch_row_prep(h))) return rc;
-    if (tuning == 1) if ((rc = launch_row_stats(h, false))) return rc;
+    if ((rc = launch_row_prep(h, tuning))) return rc;
+    if (tuning == 1 && !use_merged(h, tuning)) if ((rc = launch_row_stats(h, false))) return rc;
     if ((rc = launch_build_R(h))) return rc;
     if (cov < h->c) rc = row_update(h, cov, -1, tuning, lambda);
     else rc = row_update(h, 0, cov - h->c, tuning, lambda);

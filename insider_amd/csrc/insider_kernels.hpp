@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(64) k_level_partial(LevelArgs a)
 // Stage 2a: per level, the sum of its chunk partials (vectors of `len` doubles) in a fixed order: block = 16 outputs x
 // 16 strided groups of chunks, then the 16 group sums in group order.  grid = (ceil(len / 16), L).
 __global__ void __launch_bounds__(256) k_level_sum(const double *__restrict__ part, const int *__restrict__ lvl_chunk_ptr,
-                                                   int len, double *__restrict__ out /*[L][len]*/)
+                                                   int len, double *__restrict__ out /*[L][out_stride]*/, int out_stride)
 {
     __shared__ double red[16][17];
     const int ol = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -1057,7 +1057,7 @@ __global__ void __launch_bounds__(256) k_level_sum(const double *__restrict__ pa
         double t = 0.0;
 #pragma unroll
         for (int m = 0; m < 16; ++m) t += red[m][ol];
-        out[(size_t)l * len + o] = t;
+        out[(size_t)l * out_stride + o] = t;
     }
 }
 
@@ -1234,8 +1234,9 @@ __global__ void __launch_bounds__(256) k_line_sumsq(const double *__restrict__ v
     }
 }
 
-// S[j][off_i + l] = sum_{r in level l of covariate i} x_rj    (fixed member order)
-__global__ void __launch_bounds__(256) k_level_sums(const double *__restrict__ vals, int64_t pitch, int p,
+// S[j][off_i + l] = sum_{r in level l of covariate i} x_rj    (fixed member order); with `codes`: train entries only
+__global__ void __launch_bounds__(256) k_level_sums(const double *__restrict__ vals, const uint8_t *__restrict__ codes,
+                                                    int64_t pitch, int p,
                                                     const int *__restrict__ members_all /*c x n*/,
                                                     const int *__restrict__ lvl_ptr_all /*SL + c*/,
                                                     const int *__restrict__ lvl_off, int c, int n, int SL, int SLP,
@@ -1250,7 +1251,10 @@ __global__ void __launch_bounds__(256) k_level_sums(const double *__restrict__ v
     const int *ptr = lvl_ptr_all + lvl_off[i] + i;   // covariate i's CSR pointer array (L_i + 1 entries)
     const int *mem = members_all + (size_t)i * n;
     double s = 0.0;
-    for (int m = ptr[l]; m < ptr[l + 1]; ++m) s += vals[(size_t)j * pitch + mem[m]];
+    for (int m = ptr[l]; m < ptr[l + 1]; ++m) {
+        const size_t a = (size_t)j * pitch + mem[m];
+        if (!codes || (codes[a] & CODE_TRAIN)) s += vals[a];
+    }
     S[(size_t)j * SLP + gl] = s;
 }
 
@@ -1378,3 +1382,4 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
 #include "insider_cd_row16.hpp"
 #include "insider_cd_reg.hpp"
 #include "insider_ridge_reg.hpp"
+#include "insider_row_merged.hpp"

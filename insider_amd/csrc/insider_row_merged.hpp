@@ -1,0 +1,301 @@
+// insider_row_merged.hpp — the masked row update (optimize_row, src/optimize.cpp:150-176) without per-sample
+// statistics: categorical covariates only.
+//
+// For covariate i, level l, H(j) the held-out samples of gene j and s_r = sum_{m != i} A_m[level_m(r)]:
+//   XtX_l = sum_{r in l} (CC' - Hc_r)            = |l| CC' - sum_j m_lj c_j c_j',      m_lj = |l ∩ H(j)|
+//   Xty_l = sum_{r in l} sum_{j train} c_j (x_rj - c_j's_r)
+//         = (S_i^train C')[l] - CC' sum_{r in l} s_r + sum_j u_j[l] c_j,
+//     u_j[l] = sum_{r in l ∩ H(j)} c_j's_r = sum_{r in l ∩ H(j)} sum_{m != i} (A_m c_j)[level_m(r)].
+// The rank-one term c_j c_j' is shared by all held-out samples of gene j inside a level, so the K x K work is one
+// WEIGHTED rank-one update per (level, gene) pair — 5.5e6 pairs against 5e7 held-out entries at c3 — and every held-out
+// entry costs one table look-up and one add.  Everything that depends on the data only is built once per data set:
+// the genes' held-out samples grouped by level (per covariate), the (level -> gene, count) lists, the train-only
+// per-level sums S^train, and the level-pair sample counts that give sum_{r in l} s_r.  All terms stay sums over genes,
+// so gene-axis sharding reduces them with the same all-reduce as before.
+#pragma once
+
+namespace insider {
+
+// ---- once per data set -------------------------------------------------------------------------------------------
+// grp[j][l] (absolute positions into the gene's slice of the sorted-entry array, which reuses the column list's
+// offsets): start of the held-out samples of gene j that fall into level l of this covariate; grp[j][L] = end.
+__global__ void __launch_bounds__(256) k_group_count(const uint32_t *__restrict__ col_ptr, const int *__restrict__ col_idx,
+                                                     const int *__restrict__ lev /*n*/, int L, int p,
+                                                     uint32_t *__restrict__ grp /*[p][L + 1]*/)
+{
+    extern __shared__ int s_hist[];   // [4][L]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= p) return;
+    int *hist = s_hist + w * L;
+    for (int l = lane; l < L; l += WAVE) hist[l] = 0;
+    wave_sync();
+    for (uint32_t e = col_ptr[j] + lane; e < col_ptr[j + 1]; e += WAVE) {
+        const int r = col_idx[e];
+        if (r != LIST_PAD) atomicAdd(&hist[lev[r]], 1);   // integer counts: order-independent
+    }
+    wave_sync();
+    // exclusive scan: each lane owns a contiguous run of levels
+    const int seg = (L + WAVE - 1) / WAVE, l0 = lane * seg, l1 = l0 + seg < L ? l0 + seg : L;
+    int run = 0;
+    for (int l = l0; l < l1; ++l) run += hist[l];
+    int incl = run;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int t = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += t;
+    }
+    uint32_t pos = col_ptr[j] + (uint32_t)(incl - run);
+    uint32_t *g = grp + (size_t)j * (L + 1);
+    for (int l = l0; l < l1; ++l) { g[l] = pos; pos += (uint32_t)hist[l]; }
+    if (lane == WAVE - 1) g[L] = col_ptr[j] + (uint32_t)incl;
+}
+
+// For every gene, its held-out samples stably grouped by this covariate's level (ascending sample id inside a group);
+// what is kept per entry is not the sample id but the STACKED level index of each OTHER covariate (uint16, one
+// plane of `entries` values per other covariate, in covariate order): all the merged update needs from an entry.
+__global__ void __launch_bounds__(256) k_group_fill(const uint32_t *__restrict__ col_ptr, const int *__restrict__ col_idx,
+                                                    const int *__restrict__ lev_all /*c x n*/, const int *__restrict__ lvl_off,
+                                                    int c, int n, int cov, int L, int p, const uint32_t *__restrict__ grp,
+                                                    uint16_t *__restrict__ slev, size_t plane)
+{
+    extern __shared__ int s_hist[];   // [4][L]: running cursor per level
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= p) return;
+    int *cur = s_hist + w * L;
+    const uint32_t *g = grp + (size_t)j * (L + 1);
+    const int *lev = lev_all + (size_t)cov * n;
+    for (int l = lane; l < L; l += WAVE) cur[l] = (int)g[l];
+    wave_sync();
+    const uint64_t lt = lanemask_lt(lane);
+    for (uint32_t base = col_ptr[j]; base < col_ptr[j + 1]; base += WAVE) {
+        const uint32_t e = base + lane;
+        const int r = e < col_ptr[j + 1] ? col_idx[e] : LIST_PAD;
+        const int l = r != LIST_PAD ? lev[r] : -1;
+        uint64_t todo = __ballot(l >= 0);
+        while (todo) {                                    // one round per distinct level among the 64 entries
+            const int lead = __ffsll((unsigned long long)todo) - 1;
+            const int ll = __builtin_amdgcn_readlane(l, lead);
+            const uint64_t same = __ballot(l == ll);
+            const int c0 = cur[ll];
+            if (l == ll) {
+                const size_t pos = (size_t)c0 + __popcll(same & lt);
+                int o = 0;
+                for (int m = 0; m < c; ++m)
+                    if (m != cov) slev[(size_t)(o++) * plane + pos] = (uint16_t)(lvl_off[m] + lev_all[(size_t)m * n + r]);
+            }
+            wave_sync();
+            if (lane == lead) cur[ll] = c0 + __popcll(same);
+            wave_sync();
+            todo &= ~same;
+        }
+    }
+}
+
+// ---- per outer iteration and covariate -----------------------------------------------------------------------------
+// V[j][q] = (A c_j)[q] for every stacked level q: the small product C A' (p x K times K x SL), 64 genes x 64 levels
+// per block, 4 x 4 outputs per thread, operands staged through LDS.
+__global__ void __launch_bounds__(256) k_gene_v(const double *__restrict__ C /*p x KP*/, const double *__restrict__ Astack
+                                                /*SL x KP*/, int p, int SL, int SLP, int K, int KP, double *__restrict__ V)
+{
+    __shared__ double s_c[64][65], s_a[64][65];   // [gene or level][k], padded: k-major reads are conflict-free
+    const int j0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
+    const int tg = threadIdx.x >> 4, tq = threadIdx.x & 15;
+    for (int i = threadIdx.x; i < 64 * KP; i += 256) {
+        const int r = i / KP, k = i % KP;
+        s_c[r][k] = j0 + r < p ? C[(size_t)(j0 + r) * KP + k] : 0.0;
+        s_a[r][k] = q0 + r < SL ? Astack[(size_t)(q0 + r) * KP + k] : 0.0;
+    }
+    __syncthreads();
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double cv[4], av[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { cv[a] = s_c[tg + 16 * a][k]; av[a] = s_a[tq + 16 * a][k]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = fma(cv[a], av[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + tg + 16 * a, q = q0 + tq + 16 * b;
+            if (j < p && q < SLP) V[(size_t)j * SLP + q] = q < SL ? acc[a][b] : 0.0;
+        }
+}
+
+// U[j][l] = sum over the held-out samples r of gene j in level l of sum_{m != cov} (A_m c_j)[level_m(r)].  One wave
+// per gene: its row of V goes to LDS; then, 64 levels at a time (their held-out samples are one contiguous range of
+// the level-sorted list), lanes walk the range entry-wise in tiles (coalesced uint16 reads), leave each entry's
+// value in LDS, and lane l adds up its own group in list order (fixed order: bitwise reproducible).
+constexpr int GU_TILE = 512;    // entries per tile (LDS doubles per wave)
+
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64)
+k_gene_u(const uint32_t *__restrict__ grp, const uint16_t *__restrict__ slev, size_t plane, int nother, int L, int LP,
+         const double *__restrict__ V, int SLP, int p, int SL, double *__restrict__ U)
+{
+    extern __shared__ double s_gu[];   // [WPB][SL + GU_TILE]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * WPB + w;
+    if (j >= p) return;
+    double *v = s_gu + (size_t)w * (SL + GU_TILE), *val = v + SL;
+    for (int q = lane; q < SL; q += WAVE) v[q] = V[(size_t)j * SLP + q];
+    wave_sync();
+    const uint32_t *g = grp + (size_t)j * (L + 1);
+    for (int l0 = 0; l0 < LP; l0 += WAVE) {
+        const int l = l0 + lane;
+        const int lhi = l0 + WAVE < L ? l0 + WAVE : L;
+        const uint32_t gb = l < L ? g[l] : 0, ge = l < L ? g[l + 1] : 0;      // this lane's group
+        const uint32_t r0 = g[l0 < L ? l0 : L], r1 = g[lhi];                    // the 64 levels' range (wave-uniform)
+        double acc = 0.0;
+        for (uint32_t t0 = r0; t0 < r1; t0 += GU_TILE) {
+            const uint32_t t1 = t0 + GU_TILE < r1 ? t0 + GU_TILE : r1;
+            for (uint32_t t = t0 + lane; t < t1; t += WAVE) {
+                double x = 0.0;
+                for (int o = 0; o < nother; ++o) x += v[slev[(size_t)o * plane + t]];
+                val[t - t0] = x;
+            }
+            wave_sync();
+            const uint32_t b = gb > t0 ? gb : t0, e = ge < t1 ? ge : t1;
+            for (uint32_t t = b; t < e; ++t) acc += val[t - t0];
+            wave_sync();
+        }
+        if (l < LP) U[(size_t)j * LP + l] = acc;
+    }
+}
+
+// weighted SYRK over (gene, weight) lists: stat[item] = lower 16x16 blocks of sum_e w_e c_e c_e' for the list range
+// [item_begin, item_end) (multiples of LIST_ALIGN; padding = (LIST_PAD, 0.0)).  Same pipeline as k_list_stats; the
+// weight scales the A operand (NB extra multiplies per four entries), the value slot of the row is not used.
+template <int NB>
+__device__ __forceinline__ void wsyrk_load(const int *li, const double *lw, int batch, __amdgpu_buffer_rsrc_t rsrc,
+                                           double (&a)[SYRK_GB][NB], double (&aw)[SYRK_GB][NB], int lane)
+{
+    constexpr int RB = Geo<NB>::KP * 8;
+    const int sub = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int u = 0; u < SYRK_GB; ++u) {
+        const int idx = li[SYRK_BATCH * batch + 4 * u + sub];
+        const double wv = lw[SYRK_BATCH * batch + 4 * u + sub];
+        const int off = idx * RB + c16 * 8;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const v2i x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 128 * b, 0);
+            a[u][b] = __hiloint2double(x.y, x.x);
+            aw[u][b] = a[u][b] * wv;
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void wsyrk_mfma(const double (&a)[SYRK_GB][NB], const double (&aw)[SYRK_GB][NB],
+                                           d4 (&acc)[Geo<NB>::NBLK])
+{
+#pragma unroll
+    for (int u = 0; u < SYRK_GB; ++u) {
+        int blk = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj, ++blk)
+                acc[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[u][bi], a[u][bj], acc[blk], 0, 0, 0);
+    }
+}
+
+template <int NB, int WPB>
+__global__ void __launch_bounds__(WPB * 64)
+k_wsyrk(const uint32_t *__restrict__ item_begin, const uint32_t *__restrict__ item_end, int nitems,
+        const int *__restrict__ lidx, const double *__restrict__ lw, const double *__restrict__ F, int64_t f_rows,
+        double *__restrict__ stat)
+{
+    constexpr int NBLK = Geo<NB>::NBLK;
+    __shared__ int s_li[WPB][2][LIST_BLOCK];
+    __shared__ double s_lw[WPB][2][LIST_BLOCK];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = blockIdx.x * WPB + w;
+    if (item >= nitems) return;
+    d4 acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    const uint32_t first = item_begin[item], last = item_end[item];
+    if (first < last) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(F), 0, (int)(f_rows * Geo<NB>::KP * 8), 0x00020000);
+        const int nblk = __builtin_amdgcn_readfirstlane((int)((last - first + LIST_BLOCK - 1) / LIST_BLOCK));
+        const int nbt = __builtin_amdgcn_readfirstlane((int)((last - first) / SYRK_BATCH));   // even
+        constexpr int EPL = LIST_BLOCK / WAVE;
+        int ia[EPL], ib[EPL];
+        double xa[EPL], xb[EPL];
+        auto ld = [&](int blk, int (&ii)[EPL], double (&xx)[EPL]) {
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                const uint32_t e = first + (uint32_t)blk * LIST_BLOCK + (uint32_t)(t * WAVE + lane);
+                const uint32_t ec = e < last ? e : last - 1;
+                const int iv = lidx[ec];
+                const double xv = lw[ec];
+                ii[t] = e < last ? iv : LIST_PAD;
+                xx[t] = e < last ? xv : 0.0;
+            }
+        };
+        ld(0, ia, xa);
+        ld(1, ib, xb);
+        for (int blk = 0; blk < nblk; ++blk) {
+            int *li = s_li[w][blk & 1];
+            double *lx = s_lw[w][blk & 1];
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) { li[t * WAVE + lane] = ia[t]; lx[t * WAVE + lane] = xa[t]; }
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) { ia[t] = ib[t]; xa[t] = xb[t]; }
+            ld(blk + 2, ib, xb);
+            wave_sync();
+            const int left = nbt - blk * (LIST_BLOCK / SYRK_BATCH);
+            const int nbatch = __builtin_amdgcn_readfirstlane(left < LIST_BLOCK / SYRK_BATCH ? left : LIST_BLOCK / SYRK_BATCH);
+            double a0[SYRK_GB][NB], w0[SYRK_GB][NB], a1[SYRK_GB][NB], w1[SYRK_GB][NB];
+            wsyrk_load<NB>(li, lx, 0, rsrc, a0, w0, lane);
+            for (int b = 0; b < nbatch; b += 2) {
+                wsyrk_load<NB>(li, lx, b + 1, rsrc, a1, w1, lane);
+                wsyrk_mfma<NB>(a0, w0, acc);
+                wsyrk_load<NB>(li, lx, b + 2 < nbatch ? b + 2 : nbatch - 1, rsrc, a0, w0, lane);
+                wsyrk_mfma<NB>(a1, w1, acc);
+            }
+        }
+    }
+    double *out = stat + (size_t)item * Geo<NB>::STAT;
+    const int sub = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[b * 256 + (sub + 4 * r) * 16 + c16] = acc[b][r];
+}
+
+// the tail of a level's summed-partials record (see k_level_reduce): v = (U'C)[l], sum_{r in l} s_r from the
+// level-pair sample counts, and |l|
+__global__ void __launch_bounds__(64) k_level_pack(const double *__restrict__ Y /*[L][KP]*/,
+                                                   const double *__restrict__ paircnt /*[L][SL]*/, int SL,
+                                                   const double *__restrict__ Astack, const int *__restrict__ lvl_count,
+                                                   int L, int K, int KP, int stat_len, double *__restrict__ rec)
+{
+    const int l = blockIdx.x, lane = threadIdx.x;
+    if (l >= L) return;
+    double *out = rec + (size_t)l * (stat_len + 2 * KP + 2) + stat_len;
+    if (lane < KP) {
+        double ss = 0.0;
+        if (lane < K)
+            for (int q = 0; q < SL; ++q) {
+                const double cnt = paircnt[(size_t)l * SL + q];
+                if (cnt != 0.0) ss = fma(cnt, Astack[(size_t)q * KP + lane], ss);
+            }
+        out[lane] = lane < K ? Y[(size_t)l * KP + lane] : 0.0;
+        out[KP + lane] = ss;
+    }
+    if (lane == 0) { out[2 * KP] = (double)lvl_count[l]; out[2 * KP + 1] = 0.0; }
+}
+
+}  // namespace insider
