@@ -546,7 +546,7 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
                                h->wpart);
             hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), L), dim3(256), 0, h->stream, (const double *)h->wpart,
                                (const int *)ct.lvl_item_ptr, STAT_, h->lvl_sum, PLEN);
-            hipLaunchKernelGGL(k_level_pack, dim3(L), dim3(64), 0, h->stream, (const double *)h->Ylvl,
+            hipLaunchKernelGGL(k_level_pack, dim3(L), dim3(256), 0, h->stream, (const double *)h->Ylvl,
                                (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
                                (const int *)(h->lvl_count_all + h->lvl_off[i]), L, h->K, KP, STAT_, h->lvl_sum);
             hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(L), dim3(64), 0, h->stream, ra);
@@ -997,7 +997,7 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     // ---- merged masked row update: per covariate, the genes' held-out samples grouped by level, the (gene, count)
     // lists of every level and the level-pair sample counts (insider_row_merged.hpp) -------------------------------------
     if (m == 0) {
-        constexpr uint32_t SEG = 2048;   // list entries per weighted-SYRK work item (multiple of LIST_ALIGN)
+        constexpr uint32_t SEG = 1024;   // list entries per weighted-SYRK work item (multiple of LIST_ALIGN)
         std::vector<int> lev0((size_t)c * n);
         CH(hipMemcpy(lev0.data(), h->lev, lev0.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (int i = 0; i < c; ++i) {

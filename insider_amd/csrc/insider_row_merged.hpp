@@ -150,24 +150,55 @@ k_gene_u(const uint32_t *__restrict__ grp, const uint16_t *__restrict__ slev, si
     wave_sync();
     const uint32_t *g = grp + (size_t)j * (L + 1);
     for (int l0 = 0; l0 < LP; l0 += WAVE) {
-        const int l = l0 + lane;
+        // nl levels in this pass, T lanes per level (T a power of two, the same for every gene: fixed summation order)
         const int lhi = l0 + WAVE < L ? l0 + WAVE : L;
-        const uint32_t gb = l < L ? g[l] : 0, ge = l < L ? g[l + 1] : 0;      // this lane's group
-        const uint32_t r0 = g[l0 < L ? l0 : L], r1 = g[lhi];                    // the 64 levels' range (wave-uniform)
+        const int nl = lhi > l0 ? lhi - l0 : 1;
+        int T = 1;
+        while (2 * T * nl <= WAVE) T *= 2;
+        const int lvl = lane / T, sub = lane % T, l = l0 + lvl;
+        const bool mine = lvl < nl && l < L;
+        const uint32_t gb = mine ? g[l] : 0, ge = mine ? g[l + 1] : 0;          // this lane's group
+        const uint32_t r0 = g[l0 < L ? l0 : L], r1 = g[lhi > l0 ? lhi : L];      // the pass's range (wave-uniform)
         double acc = 0.0;
         for (uint32_t t0 = r0; t0 < r1; t0 += GU_TILE) {
             const uint32_t t1 = t0 + GU_TILE < r1 ? t0 + GU_TILE : r1;
-            for (uint32_t t = t0 + lane; t < t1; t += WAVE) {
-                double x = 0.0;
-                for (int o = 0; o < nother; ++o) x += v[slev[(size_t)o * plane + t]];
-                val[t - t0] = x;
+            for (uint32_t t = t0 + lane; t < t1; t += 4 * WAVE) {   // four entries per lane in flight
+                double x[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int o = 0; o < nother; ++o) {
+                    int q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t tu = t + u * WAVE;
+                        q[u] = slev[(size_t)o * plane + (tu < t1 ? tu : t1 - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] += v[q[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t tu = t + u * WAVE;
+                    if (tu < t1) val[tu - t0] = x[u];
+                }
             }
             wave_sync();
             const uint32_t b = gb > t0 ? gb : t0, e = ge < t1 ? ge : t1;
-            for (uint32_t t = b; t < e; ++t) acc += val[t - t0];
+            // sub-lane `sub` takes entries b + sub, b + sub + T, ... of the group (positions relative to the GROUP start,
+            // so that the split does not depend on the tiling)
+            uint32_t t = b + ((sub + T - ((b - gb) % T)) % T);
+            for (; t < e; t += T) acc += val[t - t0];
             wave_sync();
         }
-        if (l < LP) U[(size_t)j * LP + l] = acc;
+        // the T partial sums of a level, added in sub-lane order
+        val[lane] = acc;
+        wave_sync();
+        if (sub == 0 && mine) {
+            double tot = 0.0;
+            for (int q = 0; q < T; ++q) tot += val[lane + q];
+            U[(size_t)j * LP + l] = tot;
+        }
+        if (lane == 0)
+            for (int lz = L > l0 ? L : l0; lz < l0 + WAVE && lz < LP; ++lz) U[(size_t)j * LP + lz] = 0.0;   // pitch padding
+        wave_sync();
     }
 }
 
@@ -276,26 +307,28 @@ k_wsyrk(const uint32_t *__restrict__ item_begin, const uint32_t *__restrict__ it
 }
 
 // the tail of a level's summed-partials record (see k_level_reduce): v = (U'C)[l], sum_{r in l} s_r from the
-// level-pair sample counts, and |l|
-__global__ void __launch_bounds__(64) k_level_pack(const double *__restrict__ Y /*[L][KP]*/,
-                                                   const double *__restrict__ paircnt /*[L][SL]*/, int SL,
-                                                   const double *__restrict__ Astack, const int *__restrict__ lvl_count,
-                                                   int L, int K, int KP, int stat_len, double *__restrict__ rec)
+// level-pair sample counts, and |l|.  Block = one level: 4 strided groups of stacked levels x 64 coordinates, the four
+// partial sums added in group order.
+__global__ void __launch_bounds__(256) k_level_pack(const double *__restrict__ Y /*[L][KP]*/,
+                                                    const double *__restrict__ paircnt /*[L][SL]*/, int SL,
+                                                    const double *__restrict__ Astack, const int *__restrict__ lvl_count,
+                                                    int L, int K, int KP, int stat_len, double *__restrict__ rec)
 {
-    const int l = blockIdx.x, lane = threadIdx.x;
+    __shared__ double red[4][64];
+    const int l = blockIdx.x, k = threadIdx.x & 63, g = threadIdx.x >> 6;
     if (l >= L) return;
+    double ss = 0.0;
+    if (k < K)
+        for (int q = g; q < SL; q += 4) ss = fma(paircnt[(size_t)l * SL + q], Astack[(size_t)q * KP + k], ss);
+    red[g][k] = ss;
+    __syncthreads();
+    if (g != 0) return;
     double *out = rec + (size_t)l * (stat_len + 2 * KP + 2) + stat_len;
-    if (lane < KP) {
-        double ss = 0.0;
-        if (lane < K)
-            for (int q = 0; q < SL; ++q) {
-                const double cnt = paircnt[(size_t)l * SL + q];
-                if (cnt != 0.0) ss = fma(cnt, Astack[(size_t)q * KP + lane], ss);
-            }
-        out[lane] = lane < K ? Y[(size_t)l * KP + lane] : 0.0;
-        out[KP + lane] = ss;
+    if (k < KP) {
+        out[k] = k < K ? Y[(size_t)l * KP + k] : 0.0;
+        out[KP + k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
     }
-    if (lane == 0) { out[2 * KP] = (double)lvl_count[l]; out[2 * KP + 1] = 0.0; }
+    if (k == 0) { out[2 * KP] = (double)lvl_count[l]; out[2 * KP + 1] = 0.0; }
 }
 
 }  // namespace insider
