@@ -93,7 +93,8 @@ int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, 
  * include/insider_perm.h, 1 = cyclic), "profile" (1 = time the statistics / solve kernels with HIP events),
  * "verbose" (1 = print the reference's per-checkpoint lines to stdout), "cd_variant" (elastic-net sweep kernel for
  * K <= 32: 0 = four genes per wavefront with the Gram matrix in registers, 2 = four genes per wavefront with the Gram
- * matrix in LDS, 1 = one lane group per gene; all three produce the same iterates), "force_allreduce" (1 = call the all-reduce callback even
+ * matrix in LDS, 1 = one lane group per gene; all three produce the same iterates), "row_merged" (1, default = masked
+ * row update from per-(level, gene) weighted terms, 0 = from per-sample statistics; same results), "force_allreduce" (1 = call the all-reduce callback even
  * when world == 1: plumbing rehearsal). */
 int insider_hip_set_option(insider_hip_handle *h, const char *name, double value);
 
