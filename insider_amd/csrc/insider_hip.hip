@@ -996,7 +996,8 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     }
     // ---- merged masked row update: per covariate, the genes' held-out samples grouped by level, the (gene, count)
     // lists of every level and the level-pair sample counts (insider_row_merged.hpp) -------------------------------------
-    if (m == 0) {
+    // (k_gene_u keeps a gene's SLcat look-up values per wave in LDS: beyond ~1500 stacked levels the per-sample path stays)
+    if (m == 0 && (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double) <= 64 * 1024) {
         constexpr uint32_t SEG = 1024;   // list entries per weighted-SYRK work item (multiple of LIST_ALIGN)
         std::vector<int> lev0((size_t)c * n);
         CH(hipMemcpy(lev0.data(), h->lev, lev0.size() * sizeof(int), hipMemcpyDeviceToHost));
