@@ -1,0 +1,167 @@
+// insider_col_factored.hpp — the column-side masked Gram / XtY complement statistics without one rank-one update per
+// held-out entry: categorical covariates only.
+//
+// For gene j with held-out samples H(j) and row factor rows r_i = sum_m a^m[level_m(i)] (src/optimize.cpp:216-222):
+//   Gc_j = sum_{i in H(j)} r_i r_i' = M + M',   M = sum_o sum_{l in levels(o)} a^o_l p_{jl}',
+//   p_{jl} = 1/2 n_{jl} a^o_l + sum_{i in l ∩ H(j)} sum_{m after o} a^m[level_m(i)],      n_{jl} = |l ∩ H(j)|,
+// with the covariates taken in order of decreasing level count ("m after o").  (Expanding r r' over the covariates gives
+// the squares a^m a^m' and the ordered cross terms a^o a^m'; M holds half of every square and one of each pair of cross
+// terms.)  So the K x K work is one rank-one term a p' per (covariate, level) — 110 per gene at c3 against ~1000
+// held-out entries — and every held-out entry costs one K-vector add of a row of a SMALL table (the covariates after
+// the first have few levels; their rows live in LDS).  The x-dependent statistics need no pass at all:
+//   qc_j = sum_{i in H(j)} x_ij r_i = sum_l A_l' (S - S^train)[j][l],    sum_{H(j)} x^2 = yy_all - yy_train.
+// Output: the same block layout as k_list_stats (lower 16x16 blocks of the (KP x KP) matrix with qc in row KP-1 and the
+// sum of squares in its corner), so the solve kernels do not change.  The level-grouped entry lists are those of the
+// merged row update (insider_row_merged.hpp).
+#pragma once
+
+namespace insider {
+
+constexpr int CF_MAXC = 8;        // covariates
+constexpr int CF_CAP = 2048;      // uint16 look-up indices staged per wave (entries x later covariates)
+
+struct ColFacArgs {
+    int p, K, c;
+    size_t plane;                         // entries per plane of slev
+    const uint32_t *grp[CF_MAXC];         // position t (descending level count): [p][L + 1]
+    const uint16_t *slev[CF_MAXC];        // its planes (stacked level of every other covariate, covariate order)
+    int L[CF_MAXC], off[CF_MAXC];         // levels and stacked offset of the covariate at position t
+    int nlater[CF_MAXC];
+    int later_plane[CF_MAXC][CF_MAXC];    // plane index inside slev[t] of each later covariate
+    int tab_skip_lo, tab_skip_n;          // stacked levels [lo, lo + n) (position 0) are not in the LDS table
+    int tab_rows;                         // SLcat - tab_skip_n
+    const double *Astack;                 // SLcat x KP
+    const double *Qheld;                  // p x KP: sum_l A_l' (S - S^train)[j][l]
+    const double *yy_all, *yy_train;
+    double *stat;                         // [p][STAT]
+};
+
+template <int NB, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_col_factored(ColFacArgs a)
+{
+    constexpr int KP = Geo<NB>::KP, NBLK = Geo<NB>::NBLK;
+    extern __shared__ double s_cf[];   // [tab_rows + 1][KP] table | per wave: 16 x 17 transpose scratch | per wave: CF_CAP uint16
+    double *tab = s_cf;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *tr = tab + (size_t)(a.tab_rows + 1) * KP + (size_t)w * 16 * 17;
+    uint16_t *stg = reinterpret_cast<uint16_t *>(tab + (size_t)(a.tab_rows + 1) * KP + (size_t)WPB * 16 * 17) + (size_t)w * CF_CAP;
+    for (int i = threadIdx.x; i < (a.tab_rows + 1) * KP; i += WPB * 64) {   // + one all-zero row
+        const int r = i / KP, k = i % KP;
+        const int q = r < a.tab_skip_lo ? r : r + a.tab_skip_n;
+        tab[i] = r < a.tab_rows ? a.Astack[(size_t)q * KP + k] : 0.0;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * WPB + w;
+    if (j >= a.p) return;
+    const int g4 = lane >> 4, c16 = lane & 15;
+    d4 acc[NB][NB];
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < NB; ++bj) acc[bi][bj] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < a.c; ++t) {
+        const uint32_t *g = a.grp[t] + (size_t)j * (a.L[t] + 1);
+        const int Lo = a.L[t], nl = a.nlater[t];
+        const uint32_t e0 = g[0], e1 = g[Lo];
+        // stage the look-up indices of this ordering (entries x later covariates) when they fit; else read them from memory
+        const bool staged = nl > 0 && (size_t)(e1 - e0) * nl <= (size_t)CF_CAP;
+        if (staged) {
+            for (int k = 0; k < nl; ++k) {
+                const uint16_t *src = a.slev[t] + (size_t)a.later_plane[t][k] * a.plane;
+                for (uint32_t x = e0 + lane; x < e1; x += WAVE) stg[(size_t)k * (e1 - e0) + (x - e0)] = src[x];
+            }
+        }
+        wave_sync();
+        // the group bounds and factor rows of the NEXT four levels are fetched while the current four are processed
+        uint32_t bn, en;
+        double avn[NB];
+        auto fetch = [&](int l0n) {
+            const int lgn = l0n + g4;
+            const bool vn = lgn < Lo;
+            const int lc = vn ? lgn : Lo - 1;
+            const uint32_t gb = g[lc], ge = g[lc + 1];
+            bn = vn ? gb : 0;
+            en = vn ? ge : 0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                const double x = a.Astack[(size_t)(a.off[t] + lc) * KP + 16 * bb + c16];
+                avn[bb] = vn ? x : 0.0;
+            }
+        };
+        fetch(0);
+        for (int l0 = 0; l0 < Lo; l0 += 4) {
+            const uint32_t b = bn, e = en;
+            double av[NB], pr[NB];
+            const double hn = 0.5 * (double)(e - b);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                av[bb] = avn[bb];
+                pr[bb] = hn * av[bb];
+            }
+            fetch(l0 + 4);
+            // sixteen entries of the group at a time: lane c16 fetches the look-up index of entry xb + c16, the indices go
+            // round the quarter-wave by DPP row broadcast, and the 16 x NB table reads are independent (no serial LDS chain);
+            // slots beyond the group read the all-zero row of the table
+            for (int k = 0; k < nl; ++k) {
+                for (uint32_t xb = b; xb < e; xb += 16) {
+                    const uint32_t x = xb + c16;
+                    int q = a.tab_rows;
+                    if (x < e) {
+                        q = staged ? (int)stg[(size_t)k * (e1 - e0) + (x - e0)]
+                                   : (int)a.slev[t][(size_t)a.later_plane[t][k] * a.plane + x];
+                        q = q < a.tab_skip_lo ? q : q - a.tab_skip_n;
+                    }
+                    const int qo = q * KP + c16;
+#define CF_ADD(U)                                                                                   \
+    {                                                                                               \
+        const int qu = __builtin_amdgcn_update_dpp(0, qo, 0x150 + (U), 0xf, 0xf, true) - (U) + c16; \
+        _Pragma("unroll") for (int bb = 0; bb < NB; ++bb) pr[bb] += tab[qu + 16 * bb];              \
+    }
+                    CF_ADD(0) CF_ADD(1) CF_ADD(2) CF_ADD(3) CF_ADD(4) CF_ADD(5) CF_ADD(6) CF_ADD(7)
+                    CF_ADD(8) CF_ADD(9) CF_ADD(10) CF_ADD(11) CF_ADD(12) CF_ADD(13) CF_ADD(14) CF_ADD(15)
+#undef CF_ADD
+                }
+            }
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < NB; ++bj)
+                    acc[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[bi], pr[bj], acc[bi][bj], 0, 0, 0);
+        }
+        wave_sync();
+    }
+    // ---- Gc = M + M' for the lower blocks; qc and the sum of squares go into row KP - 1 ---------------------------
+    double *out = a.stat + (size_t)j * Geo<NB>::STAT;
+    const double ss = a.yy_all[j] - a.yy_train[j];
+    int blk = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj, ++blk) {
+            // transpose M(bj, bi) through LDS: register r of lane l holds element ((l >> 4) + 4 r, l & 15)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(g4 + 4 * r) * 17 + c16] = acc[bj][bi][r];
+            wave_sync();
+            d4 res;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) res[r] = acc[bi][bj][r] + tr[c16 * 17 + g4 + 4 * r];
+            wave_sync();
+            if (bi == NB - 1 && g4 == 3) {   // global row KP - 1 = local row 15 = register 3 of lanes 48..63
+                const int col = 16 * bj + c16;
+                res[3] = col < a.K ? a.Qheld[(size_t)j * KP + col] : (col == KP - 1 ? ss : 0.0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[blk * 256 + (g4 + 4 * r) * 16 + c16] = res[r];
+        }
+    (void)NBLK;
+}
+
+// Sheld = S - Strain (once per data set)
+__global__ void __launch_bounds__(256) k_sub(const double *__restrict__ a, const double *__restrict__ b, size_t n,
+                                             double *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = a[t] - b[t];
+}
+
+}  // namespace insider

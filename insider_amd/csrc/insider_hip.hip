@@ -106,6 +106,11 @@ struct insider_hip_handle {
     double *stat = nullptr, *stat_col = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
     double *lvl_sum = nullptr;
     double *Strain = nullptr;         // per-level sums of X over TRAIN entries (p x SLP), once per data set
+    double *Sheld = nullptr;          // S - Strain: per-level sums over the held-out entries
+    double *Qheld = nullptr;          // p x KP workspace: sum_l A_l' Sheld[j][l]
+    int col_factored = 1;             // option: factored column statistics (insider_col_factored.hpp)
+    ColFacArgs cf;                    // its static part (filled at create)
+    size_t cf_lds = 0;
     double *U = nullptr, *Ylvl = nullptr, *wpart = nullptr, *Vlev = nullptr;   // merged row update workspace
     int max_items = 0;
     bool merged = false;              // the merged masked row update is available (categorical covariates only)
@@ -144,7 +149,7 @@ namespace {
 void free_workspace(insider_hip_handle *h)
 {
     double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
-                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
+                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->Qheld, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->sweeps) (void)hipFree(h->sweeps);
@@ -207,6 +212,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
         if ((rc = dmalloc(&h->Ylvl, (size_t)std::max(h->max_L, 1) * KP))) return rc;
         if ((rc = dmalloc(&h->wpart, (size_t)std::max(h->max_items, 1) * STAT))) return rc;
         if ((rc = dmalloc(&h->Vlev, (size_t)h->p * h->SLP))) return rc;
+        if ((rc = dmalloc(&h->Qheld, (size_t)h->p * KP))) return rc;
     }
     if ((rc = dmalloc(&h->eq, (size_t)h->max_L * (KP * KP + KP)))) return rc;
     if ((rc = dmalloc(&h->sse_train, (size_t)h->p))) return rc;
@@ -340,14 +346,39 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     return INSIDER_OK;
 }
 
+// factored column statistics available and selected?  (LDS: the table of the covariates after the largest one)
+bool use_col_factored(const insider_hip_handle *h)
+{
+    return h->merged && h->col_factored && h->m == 0 && h->c <= CF_MAXC &&
+           ((size_t)(h->cf.tab_rows + 1) * h->KP + 4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2 <= 64 * 1024;
+}
+
 // masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
 int launch_col_stats(insider_hip_handle *h, bool timed)
 {
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
-    rc = launch_list_stats(h, true, 1, h->R, h->stat_col);
-    if (rc) return rc;
+    if (use_col_factored(h)) {
+        hipLaunchKernelGGL(k_qfull, dim3(cdiv(h->p, 256 / h->KP)), dim3(256), 0, h->stream, (const double *)h->Sheld, h->SL,
+                           h->SLP, (const double *)h->Astack, h->KP, (int)h->p, h->Qheld);
+        ColFacArgs a = h->cf;
+        a.K = h->K;
+        a.Astack = h->Astack;
+        a.Qheld = h->Qheld;
+        a.yy_all = h->yy_all;
+        a.yy_train = h->yy_train;
+        a.stat = h->stat_col;
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            const size_t lds = ((size_t)(a.tab_rows + 1) * Geo<NB_>::KP + (size_t)4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2;
+            hipLaunchKernelGGL((k_col_factored<NB_, 4>), dim3(cdiv(h->p, 4)), dim3(256), lds, h->stream, a);
+        });
+        KCHECK();
+    } else {
+        rc = launch_list_stats(h, true, 1, h->R, h->stat_col);
+        if (rc) return rc;
+    }
     return t.end(h, h->ev_col);
 }
 
@@ -763,6 +794,7 @@ void insider_hip_destroy(insider_hip_handle *h)
             if (q) (void)hipFree(q);
     }
     if (h->Strain) (void)hipFree(h->Strain);
+    if (h->Sheld) (void)hipFree(h->Sheld);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1061,6 +1093,32 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
             CH(hipMemcpy(ct.paircnt, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice));
         }
         h->merged = true;
+        // ---- factored column statistics: covariates by decreasing level count, the planes of the later ones ----------
+        CR(dmalloc(&h->Sheld, (size_t)p * h->SLP));
+        hipLaunchKernelGGL(k_sub, dim3(cdiv((int64_t)p * h->SLP, 256)), dim3(256), 0, h->stream, (const double *)h->S,
+                           (const double *)h->Strain, (size_t)p * h->SLP, h->Sheld);
+        CH(hipGetLastError());
+        if (c <= CF_MAXC) {
+            std::vector<int> ord(c);
+            for (int i = 0; i < c; ++i) ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return n_levels[x] > n_levels[y]; });
+            ColFacArgs &cf = h->cf;
+            cf.p = (int)p;
+            cf.c = c;
+            cf.plane = (size_t)h->col_entries + LIST_BLOCK;
+            for (int t = 0; t < c; ++t) {
+                const int o = ord[t];
+                cf.grp[t] = h->cov[o].grp;
+                cf.slev[t] = h->cov[o].slev;
+                cf.L[t] = n_levels[o];
+                cf.off[t] = h->lvl_off[o];
+                cf.nlater[t] = c - 1 - t;
+                for (int k = t + 1; k < c; ++k) cf.later_plane[t][k - t - 1] = ord[k] < o ? ord[k] : ord[k] - 1;
+            }
+            cf.tab_skip_lo = h->lvl_off[ord[0]];
+            cf.tab_skip_n = n_levels[ord[0]];
+            cf.tab_rows = h->SLcat - cf.tab_skip_n;
+        }
     }
     // the transposed copies were only needed to build the row-side lists
     (void)hipFree(h->Xt);
@@ -1095,6 +1153,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
     else if (s == "force_allreduce") h->force_allreduce = (int)value;   // call the all-reduce callback even when world == 1
+    else if (s == "col_factored") h->col_factored = (int)value;   // 1 = factored column statistics (default), 0 = k_list_stats
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update (default), 0 = per-sample statistics
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);

@@ -1383,3 +1383,4 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
 #include "insider_cd_reg.hpp"
 #include "insider_ridge_reg.hpp"
 #include "insider_row_merged.hpp"
+#include "insider_col_factored.hpp"
