@@ -94,7 +94,9 @@ int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, 
  * "verbose" (1 = print the reference's per-checkpoint lines to stdout), "cd_variant" (elastic-net sweep kernel for
  * K <= 32: 0 = four genes per wavefront with the Gram matrix in registers, 2 = four genes per wavefront with the Gram
  * matrix in LDS, 1 = one lane group per gene; all three produce the same iterates), "row_merged" (1, default = masked
- * row update from per-(level, gene) weighted terms, 0 = from per-sample statistics; same results), "force_allreduce" (1 = call the all-reduce callback even
+ * row update from per-(level, gene) weighted terms, 0 = from per-sample statistics; same results), "col_factored" (1,
+ * default = column-side masked Gram statistics from per-(covariate, level) terms when a cost model favours them, 2 =
+ * always, 0 = one rank-one update per held-out entry; same results), "force_allreduce" (1 = call the all-reduce callback even
  * when world == 1: plumbing rehearsal). */
 int insider_hip_set_option(insider_hip_handle *h, const char *name, double value);
 

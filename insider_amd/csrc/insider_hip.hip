@@ -65,6 +65,7 @@ struct CovTables {   // per covariate, device
     uint32_t *item_begin = nullptr, *item_end = nullptr;   // weighted-SYRK work items: ranges of the (gene, count) lists
     int *lvl_item_ptr = nullptr;      // [L + 1] items of every level
     int nitems = 0;
+    int64_t npairs = 0;               // (level, gene) pairs with held-out samples
     int *wl_idx = nullptr;            // (gene, count) lists of every level, padded like the held-out lists
     double *wl_w = nullptr;
     double *paircnt = nullptr;        // [L][SLcat] samples in (level of this covariate, stacked level of another one)
@@ -346,11 +347,24 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     return INSIDER_OK;
 }
 
-// factored column statistics available and selected?  (LDS: the table of the covariates after the largest one)
+// factored column statistics available and worth it?  (LDS: the table of the covariates after the largest one.)  Issue-cycle
+// model per gene with E held-out entries: the list kernel spends NBLK MFMAs (64 cycles) per 4 entries; the factored one
+// NB^2 MFMAs per 4 levels plus, per later covariate and 16-entry batch of a level group, 16 x (2 + NB) vector
+// instructions (4.6 cycles).  Measured at c3 / c5: 0.51 vs 1.30 ms (model 14.5k vs 48k cycles) and 2.44 vs 0.66 ms (72k vs 24k).
 bool use_col_factored(const insider_hip_handle *h)
 {
-    return h->merged && h->col_factored && h->m == 0 && h->c <= CF_MAXC &&
-           ((size_t)(h->cf.tab_rows + 1) * h->KP + 4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2 <= 64 * 1024;
+    if (!(h->merged && h->col_factored && h->m == 0 && h->c <= CF_MAXC)) return false;
+    if (((size_t)(h->cf.tab_rows + 1) * h->KP + 4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2 > 64 * 1024) return false;
+    if (h->col_factored == 2) return true;   // forced
+    const double E = (double)h->col_entries / (double)std::max<int64_t>(h->p, 1);
+    const int NB = h->NB;
+    const double list = E * (NB * (NB + 1) / 2) * 16.0;
+    double fac = 0.0;
+    for (int t = 0; t < h->cf.c; ++t) {
+        const double batches = std::ceil(std::max(1.0, E / h->cf.L[t]) / 16.0);
+        fac += std::ceil(h->cf.L[t] / 4.0) * (NB * NB * 64.0 + h->cf.nlater[t] * batches * 16.0 * (2 + NB) * 4.6);
+    }
+    return 1.3 * fac < list;
 }
 
 // masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
@@ -494,8 +508,34 @@ int launch_test_sse(insider_hip_handle *h, int masked, bool timed)
     return t.end(h, h->ev_test);
 }
 
-// masked update without per-sample statistics (insider_row_merged.hpp)?
-bool use_merged(const insider_hip_handle *h, int masked) { return masked && h->merged && h->row_merged && h->m == 0; }
+// masked update without per-sample statistics (insider_row_merged.hpp)?  Time model (us at c3 / c5 rates): per-sample
+// path = one rank-one MFMA group per held-out entry + the level kernels; merged path per covariate = one weighted group per
+// (level, gene) pair + one look-up per entry and other covariate + the small products over its levels.  Measured at
+// c3: 0.55 vs 1.4 ms (model 0.45 vs 1.38); at c5 (4 covariates): 1.37 vs 0.85 ms (model 1.24 vs 0.84).
+bool use_merged(const insider_hip_handle *h, int masked)
+{
+    if (!(masked && h->merged && h->row_merged && h->m == 0)) return false;
+    if (h->row_merged == 2) return true;   // forced
+    const int NB = h->NB ? h->NB : 2;
+    const double mf = (NB * (NB + 1) / 2) * 16.0 / (1024.0 * 2100.0);   // us per rank-one group entry on the whole GPU
+    const double E = (double)h->row_entries, pscale = (double)h->p / 5.0e4;
+    const double old_us = E * mf * 1.15 + 50.0 * h->c;
+    double merged_us = 0.0;
+    for (int i = 0; i < h->c; ++i)
+        merged_us += (double)h->cov[i].npairs * mf * 1.1 + E * (h->c - 1) * 1.3e-6 + 33.0 * pscale * h->SLcat / 110.0 / h->c +
+                     37.0 * pscale * h->cov[i].L / 100.0 + 40.0;
+    return 1.1 * merged_us < old_us;
+}
+
+// V = C A' for the stacked levels [q_begin, q_end) (all of them once per outer iteration, then the updated covariate's)
+int launch_gene_v(insider_hip_handle *h, int q_begin, int q_end)
+{
+    hipLaunchKernelGGL(k_gene_v, dim3(cdiv(h->p, 64), cdiv(q_end - q_begin, 64)), dim3(256), 0, h->stream,
+                       (const double *)h->C, (const double *)h->Astack, (int)h->p, q_begin, q_end, h->SLP, h->K, h->KP,
+                       h->Vlev);
+    KCHECK();
+    return INSIDER_OK;
+}
 
 int launch_row_stats(insider_hip_handle *h, bool timed)
 {
@@ -552,8 +592,6 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
     if (!cont && use_merged(h, masked)) {
         // merged update: one weighted rank-one term per (level, gene) pair, one look-up per held-out entry
         const int L = ct.L, LP = (int)round_up(L, 2), KP = h->KP;
-        hipLaunchKernelGGL(k_gene_v, dim3(cdiv(h->p, 64), cdiv(h->SLP, 64)), dim3(256), 0, h->stream, (const double *)h->C,
-                           (const double *)h->Astack, (int)h->p, h->SLcat, h->SLP, h->K, KP, h->Vlev);
         hipLaunchKernelGGL((k_gene_u<4>), dim3(cdiv(h->p, 4)), dim3(256), (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double),
                            h->stream, (const uint32_t *)ct.grp, (const uint16_t *)ct.slev,
                            (size_t)h->col_entries + LIST_BLOCK, h->c - 1, L, LP, (const double *)h->Vlev, h->SLP, (int)h->p,
@@ -1071,6 +1109,8 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
             lip[L] = (int)ib.size();
             if (widx.size() >= (1ull << 32)) { insider_hip_destroy(h); return fail(INSIDER_ERR_UNSUPPORTED, "level lists too long"); }
             ct.nitems = (int)ib.size();
+            ct.npairs = 0;
+            for (double wv : ww) ct.npairs += wv != 0.0;
             h->max_items = std::max(h->max_items, ct.nitems);
             CR(dmalloc(&ct.wl_idx, widx.size() + LIST_BLOCK));
             CR(dmalloc(&ct.wl_w, ww.size() + LIST_BLOCK));
@@ -1153,8 +1193,8 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
     else if (s == "force_allreduce") h->force_allreduce = (int)value;   // call the all-reduce callback even when world == 1
-    else if (s == "col_factored") h->col_factored = (int)value;   // 1 = factored column statistics (default), 0 = k_list_stats
-    else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update (default), 0 = per-sample statistics
+    else if (s == "col_factored") h->col_factored = (int)value;   // 1 = factored column statistics when the cost model favours them (default), 2 = always, 0 = k_list_stats
+    else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
@@ -1203,8 +1243,12 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
         if ((rc = launch_row_prep(h, masked))) return rc;                                       // :332
         if (masked && !use_merged(h, masked)) if ((rc = launch_row_stats(h, true))) return rc;
-        for (int i = 0; i < h->c; ++i)
+        if (use_merged(h, masked)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
+        for (int i = 0; i < h->c; ++i) {
             if ((rc = row_update(h, i, -1, masked, lambda1))) return rc;                        // :339
+            if (use_merged(h, masked) && i + 1 < h->c)
+                if ((rc = launch_gene_v(h, h->lvl_off[i], h->lvl_off[i + 1]))) return rc;
+        }
         if (inc_continuous)
             for (int j = 0; j < h->m; ++j)
                 if ((rc = row_update(h, 0, j, masked, lambda1))) return rc;                     // :340-351
@@ -1310,6 +1354,7 @@ int insider_hip_optimize_row(insider_hip_handle *h, double *const *A, const doub
     if ((rc = launch_row_prep(h, tuning))) return rc;
     if (tuning == 1 && !use_merged(h, tuning)) if ((rc = launch_row_stats(h, false))) return rc;
     if ((rc = launch_build_R(h))) return rc;
+    if (use_merged(h, tuning)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
     if (cov < h->c) rc = row_update(h, cov, -1, tuning, lambda);
     else rc = row_update(h, 0, cov - h->c, tuning, lambda);
     if (rc) return rc;

@@ -95,11 +95,14 @@ __global__ void __launch_bounds__(256) k_group_fill(const uint32_t *__restrict__
 // ---- per outer iteration and covariate -----------------------------------------------------------------------------
 // V[j][q] = (A c_j)[q] for every stacked level q: the small product C A' (p x K times K x SL), 64 genes x 64 levels
 // per block, 4 x 4 outputs per thread, operands staged through LDS.
+// Only the stacked levels [q_begin, q_end) are (re)computed: after a covariate's update only its own columns change.
 __global__ void __launch_bounds__(256) k_gene_v(const double *__restrict__ C /*p x KP*/, const double *__restrict__ Astack
-                                                /*SL x KP*/, int p, int SL, int SLP, int K, int KP, double *__restrict__ V)
+                                                /*SL x KP*/, int p, int q_begin, int q_end, int SLP, int K, int KP,
+                                                double *__restrict__ V)
 {
     __shared__ double s_c[64][65], s_a[64][65];   // [gene or level][k], padded: k-major reads are conflict-free
-    const int j0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
+    const int SL = q_end;
+    const int j0 = blockIdx.x * 64, q0 = q_begin + blockIdx.y * 64;
     const int tg = threadIdx.x >> 4, tq = threadIdx.x & 15;
     for (int i = threadIdx.x; i < 64 * KP; i += 256) {
         const int r = i / KP, k = i % KP;
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(256) k_gene_v(const double *__restrict__ C /*p
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j = j0 + tg + 16 * a, q = q0 + tq + 16 * b;
-            if (j < p && q < SLP) V[(size_t)j * SLP + q] = q < SL ? acc[a][b] : 0.0;
+            if (j < p && q < SL) V[(size_t)j * SLP + q] = acc[a][b];
         }
 }
 

@@ -249,10 +249,11 @@ def test_optimize_31_iterations(oracle, case):
 
 @pytest.mark.parametrize("opts", [dict(cd_variant=1), dict(cd_variant=2), dict(order_mode=1), dict(max_sweeps=7),
                                   dict(cd_variant=1, max_sweeps=5, order_mode=1),
-                                  dict(cd_variant=2, max_sweeps=6, order_mode=1), dict(row_merged=0)])
+                                  dict(cd_variant=2, max_sweeps=6, order_mode=1), dict(row_merged=0), dict(row_merged=2), dict(col_factored=0), dict(col_factored=2),
+                                  dict(row_merged=0, col_factored=0)])
 def test_optimize_options(oracle, opts):
     # the alternative CD kernels (one group of lanes per gene; LDS-resident row16), cyclic sweep order, the sweep cap,
-    # and the per-sample row update instead of the merged one
+    # the per-sample row update instead of the merged one, the per-entry column statistics instead of the factored ones
     w = workloads.small(K=9, n=70, p=90, with_na=True)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
     for k, v in opts.items():
