@@ -155,7 +155,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(name, {}).get("col_stats_bytes_per_launch")
+                tj = json.load(open(tpath)).get(name, {})
+                traffic = tj.get("col_stats_bytes_per_launch" if prof.get("col_factored") else "list_stats_col_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -168,19 +169,25 @@ def main():
                                    f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}",
                        "genes_per_gpu": p_loc, "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
                        "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_col_factored + k_qfull(held-out level sums): the column-side masked Gram/XtY complement "
-                                   "statistics of every gene (the quantity BASELINE's metric 2 names), factored form",
+            "roofline": {"kernel": ("k_col_factored + k_qfull(held-out level sums): the column-side masked Gram/XtY complement "
+                                    "statistics of every gene (the quantity BASELINE's metric 2 names), factored form")
+                                   if prof.get("col_factored") else
+                                   "k_list_stats (masked Gram/XtY complement statistics over the held-out lists, column side)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],
                          "fp64_tflops": fl / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
                          "fp64_frac": fl / (gram_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gram_ms > 0 else 0.0,
-                         "note": "achieved = SURVEY 8d's algorithmic bytes (8np X + np mask + 8nK + 8p(T+K) out) / time. "
-                                 "The factored kernel streams neither X nor the mask (x-statistics come from per-level sums built "
-                                 "once per data set; the Gram complement costs one rank-one term per (covariate, level) and "
-                                 "one table-row add per held-out entry), so measured traffic is ~0.11x the algorithmic bytes "
-                                 "and achieved can exceed the HBM peak; the same statistics from the per-entry list kernel "
-                                 "(k_list_stats, option col_factored=0) take 1.30 ms = 3.6 TB/s = 0.45 of peak, MFMA-f64-bound"},
+                         "row_update": "merged (per (level, gene) pair)" if prof.get("row_merged") else "per-sample statistics",
+                         "note": ("achieved = SURVEY 8d's algorithmic bytes (8np X + np mask + 8nK + 8p(T+K) out) / time. "
+                                  "The factored kernel streams neither X nor the mask (x-statistics come from per-level sums built "
+                                  "once per data set; the Gram complement costs one rank-one term per (covariate, level) and "
+                                  "one table-row add per held-out entry), so measured traffic is ~0.11x the algorithmic bytes "
+                                  "and achieved can exceed the HBM peak; the same statistics from the per-entry list kernel "
+                                  "(k_list_stats, option col_factored=0) take 1.30 ms at c3 = 3.6 TB/s = 0.45 of peak, MFMA-f64-bound")
+                                 if prof.get("col_factored") else
+                                 "MFMA-f64-bound: 3 v_mfma_f64_16x16x4 per 4 held-out entries (K <= 31); HBM traffic is ~0.23x the "
+                                 "algorithmic bytes (the kernel reads held-out lists, not X)"},
             "cd_kernel": {"kernel": "k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)",
                           "avg_launch_ms": prof["cd_ms"] / max(prof["cd_launches"], 1),
                           "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,

@@ -179,7 +179,8 @@ int insider_hip_masked_gram_rows(insider_hip_handle *h, const double *C, int K, 
 /* Profile of the last insider_hip_optimize() call (option "profile" = 1), HIP-event timed on the library's stream.
  * out[0..11]: {column-side masked-Gram launches, total ms, row-side masked-Gram launches, total ms,
  *  column-solve (CD / ridge) launches, total ms, test-residual launches, total ms,
- *  optimize() wall ms, outer iterations run, elastic-net sweeps total, reserved}. */
+ *  optimize() wall ms, outer iterations run, elastic-net sweeps total, path flags (1 = factored column statistics, 2 =
+ *  merged row update)}. */
 int insider_hip_get_profile(insider_hip_handle *h, double *out12);
 
 /* Diagnostics: per-gene sweep counts of the last column update (p ints), and the HIP-event time in ms of the

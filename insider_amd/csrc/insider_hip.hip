@@ -1315,6 +1315,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     h->prof[8] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     h->prof[9] = (double)std::min<uint64_t>((uint64_t)iter + 1, (uint64_t)max_iter + 1);
     h->prof[10] = (double)sweeps_total;
+    h->prof[11] = (masked && use_col_factored(h) ? 1.0 : 0.0) + (use_merged(h, masked) ? 2.0 : 0.0);   // which statistics paths ran
     clear_events(h);
     return INSIDER_OK;
 }
