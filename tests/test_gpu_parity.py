@@ -209,11 +209,19 @@ CASES = {
 }
 
 
+# the masked statistics have two implementations each (per-entry lists / factored per level); a cost model picks one
+# per data set, so every case runs with both forced
+PATHS = {"fast": dict(row_merged=2, col_factored=2), "lists": dict(row_merged=0, col_factored=0)}
+
+
+@pytest.mark.parametrize("paths", list(PATHS))
 @pytest.mark.parametrize("case", list(CASES))
-def test_optimize_one_iteration(oracle, case):
+def test_optimize_one_iteration(oracle, case, paths):
     w = workloads.small(**CASES[case])
     A, C = _rand_factors(w, 5, scale=0.3)   # non-trivial start so that every term of the update matters
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    for k, v in PATHS[paths].items():
+        ds.set_option(k, v)
     got = ds.optimize([a.copy(order="F") for a in A], C.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=w.tuning,
                       max_iter=0, seed=17)
     ds.close()
@@ -226,10 +234,13 @@ def test_optimize_one_iteration(oracle, case):
     np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
 
 
+@pytest.mark.parametrize("paths", list(PATHS))
 @pytest.mark.parametrize("case", list(CASES))
-def test_optimize_31_iterations(oracle, case):
+def test_optimize_31_iterations(oracle, case, paths):
     w = workloads.small(**CASES[case])
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    for k, v in PATHS[paths].items():
+        ds.set_option(k, v)
     got = ds.optimize([a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha,
                       tuning=w.tuning, max_iter=30, seed=23)
     ds.close()

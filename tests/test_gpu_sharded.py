@@ -19,11 +19,13 @@ CASE = dict(n=120, p=150, level_counts=(7, 4), K=9, f=0.15, seed=23, with_na=Tru
 ITERS = 12
 
 
-def _fit(rank, world, staged):
+def _fit(rank, world, staged, opts=None):
     from insider_amd import api, dist as idist
     w = workloads.small(**CASE)
     lo, hi = idist.shard_range(w.p, rank, world)
     ds = api.InsiderData(w.X[:, lo:hi], w.levels, w.M_train[:, lo:hi], w.M_test[:, lo:hi])
+    for k, v in (opts or {}).items():
+        ds.set_option(k, v)
     ar = idist.attach(ds, lo, rank, world, staged=staged)
     A = [a.copy(order="F") for a in w.A0]
     C = w.C0[:, lo:hi].copy(order="F")
@@ -33,27 +35,29 @@ def _fit(rank, world, staged):
                 loss=res["loss"], test_rmse=res["test_rmse"], lo=lo, hi=hi, calls=len(ar.calls) if ar else 0)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, opts):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank, _fit(rank, world, staged=True)))
+        q.put((rank, _fit(rank, world, staged=True, opts=opts)))
     except Exception as e:   # surface the failure in the parent instead of a hang
         q.put((rank, repr(e)))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_rank():
+@pytest.mark.parametrize("opts", [dict(row_merged=2, col_factored=2), dict(row_merged=0, col_factored=0)],
+                         ids=["merged-factored", "per-entry"])
+def test_two_ranks_on_one_gpu_match_single_rank(opts):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, opts)) for r in range(2)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=240) for _ in procs)
@@ -61,7 +65,7 @@ def test_two_ranks_on_one_gpu_match_single_rank():
         p.join(timeout=60)
     for r in (0, 1):
         assert isinstance(out[r], dict), out[r]
-    single = _fit(0, 1, staged=False)
+    single = _fit(0, 1, staged=False, opts=opts)
 
     # one all-reduce per covariate per outer iteration + one per loss checkpoint (initial fit, iterations 0 and 10)
     n_cov = len(CASE["level_counts"])
