@@ -147,6 +147,8 @@ struct insider_hip_handle {
 
 namespace {
 
+constexpr int MM_SLAB = 128;  // rows per partial of the reduction products (insider_mm.hpp)
+
 void free_workspace(insider_hip_handle *h)
 {
     double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
@@ -190,9 +192,9 @@ int ensure_workspace(insider_hip_handle *h, int K)
     nseg = std::min(nseg, 64);
     h->nseg = nseg;
     h->seg_len = 0;
-    h->gram_blocks_p = cdiv(h->p, 256);
-    h->gram_blocks_n = cdiv(h->n, 256);
-    h->sc_blocks = cdiv(h->p, 256);
+    h->gram_blocks_p = cdiv(h->p, MM_SLAB);
+    h->gram_blocks_n = cdiv(h->n, MM_SLAB);
+    h->sc_blocks = cdiv(h->p, MM_SLAB);
     int rc;
     if ((rc = dmalloc(&h->Astack, (size_t)h->SL * KP))) return rc;
     if ((rc = dmalloc(&h->R, (size_t)h->n * KP))) return rc;
@@ -274,20 +276,39 @@ int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *
     return INSIDER_OK;
 }
 
-int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *out)
+// ---- the small dense products on MFMA (insider_mm.hpp) -------------------------------------------------------------------
+// out[M x KP] = X[M x Kd] W[Kd x KP]   (W row-major with pitch KP)
+int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M, int Kd, const double *W, double *out)
 {
-    const int nb = cdiv(rows, 256);
-    switch (h->KP) {
-        case 16: hipLaunchKernelGGL((k_gram_partial<16>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
-        case 32: hipLaunchKernelGGL((k_gram_partial<32>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
-        case 48: hipLaunchKernelGGL((k_gram_partial<48>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
-        default: hipLaunchKernelGGL((k_gram_partial<64>), dim3(nb), dim3(256), 0, h->stream, F, rows, 256, h->gram_part); break;
-    }
-    KCHECK();
-    const int len = h->KP * h->KP;
-    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 16)), dim3(256), 0, h->stream, h->gram_part, nb, len, out);
+    NB_DISPATCH(h->NB, {
+        (void)WPB_;
+        hipLaunchKernelGGL((k_mm_rows<NB_, false>), dim3(cdiv(cdiv(M, 16), 4), 1), dim3(256), 0, h->stream, X, ldx, M, Kd, W,
+                           h->KP, h->KP, out, (int64_t)h->KP, h->KP);
+    });
     KCHECK();
     return INSIDER_OK;
+}
+
+// part[slab][L][KP] = sum over slabs of MM_SLAB rows of X[m][l] Y[m][n], then the fixed-order sum over slabs -> out[L][KP]
+int launch_mm_reduce_kp(insider_hip_handle *h, const double *X, int64_t ldx, const double *Y, int M, int L, double *part,
+                        double *out)
+{
+    const int slabs = cdiv(M, MM_SLAB);
+    NB_DISPATCH(h->NB, {
+        (void)WPB_;
+        hipLaunchKernelGGL((k_mm_reduce<NB_>), dim3(slabs, cdiv(L, 16)), dim3(64), 0, h->stream, X, ldx, Y, (int64_t)h->KP, M,
+                           MM_SLAB, L, h->KP, part, h->KP);
+    });
+    KCHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(L * h->KP, 16)), dim3(256), 0, h->stream, (const double *)part, slabs,
+                       L * h->KP, out);
+    KCHECK();
+    return INSIDER_OK;
+}
+
+int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *out)
+{
+    return launch_mm_reduce_kp(h, F, h->KP, F, (int)rows, h->KP, h->gram_part, out);
 }
 
 int launch_build_R(insider_hip_handle *h)
@@ -306,10 +327,7 @@ int phase_R(insider_hip_handle *h)
     if (rc) return rc;
     rc = launch_gram(h, h->R, h->n, h->RtR);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_qfull, dim3(cdiv(h->p, 256 / h->KP)), dim3(256), 0, h->stream, (const double *)h->S, h->SL,
-                       h->SLP, (const double *)h->Astack, h->KP, (int)h->p, h->Qfull);
-    KCHECK();
-    return INSIDER_OK;
+    return launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull);
 }
 
 struct Timer {   // HIP-event pair around one launch on the library's stream (option "profile")
@@ -374,8 +392,7 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
     int rc = t.begin(h, timed);
     if (rc) return rc;
     if (use_col_factored(h)) {
-        hipLaunchKernelGGL(k_qfull, dim3(cdiv(h->p, 256 / h->KP)), dim3(256), 0, h->stream, (const double *)h->Sheld, h->SL,
-                           h->SLP, (const double *)h->Astack, h->KP, (int)h->p, h->Qheld);
+        if ((rc = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld))) return rc;
         ColFacArgs a = h->cf;
         a.K = h->K;
         a.Astack = h->Astack;
@@ -530,9 +547,11 @@ bool use_merged(const insider_hip_handle *h, int masked)
 // V = C A' for the stacked levels [q_begin, q_end) (all of them once per outer iteration, then the updated covariate's)
 int launch_gene_v(insider_hip_handle *h, int q_begin, int q_end)
 {
-    hipLaunchKernelGGL(k_gene_v, dim3(cdiv(h->p, 64), cdiv(q_end - q_begin, 64)), dim3(256), 0, h->stream,
-                       (const double *)h->C, (const double *)h->Astack, (int)h->p, q_begin, q_end, h->SLP, h->K, h->KP,
-                       h->Vlev);
+    // V[:, q_begin:q_end) = C A[q_begin:q_end, :]'  (A given "transposed": one row per output column)
+    const int N = q_end - q_begin;
+    hipLaunchKernelGGL((k_mm_rows<4, true>), dim3(cdiv(cdiv((int)h->p, 16), 4), cdiv(N, 64)), dim3(256), 0, h->stream,
+                       (const double *)h->C, (int64_t)h->KP, (int)h->p, h->K, (const double *)(h->Astack + (size_t)q_begin * h->KP),
+                       h->KP, N, h->Vlev + q_begin, (int64_t)h->SLP, N);
     KCHECK();
     return INSIDER_OK;
 }
@@ -597,15 +616,8 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
                            (size_t)h->col_entries + LIST_BLOCK, h->c - 1, L, LP, (const double *)h->Vlev, h->SLP, (int)h->p,
                            h->SLcat, h->U);
         KCHECK();
-        {   // Y = U'C, the same reduction over genes as (S C')
-            const int LT = 256 / KP;
-            dim3 grid(h->sc_blocks, cdiv(L, LT));
-            hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream, (const double *)h->U, L, LP,
-                               (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
-            hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(L * KP, 16)), dim3(256), 0, h->stream,
-                               (const double *)h->sc_part, h->sc_blocks, L * KP, h->Ylvl);
-            KCHECK();
-        }
+        // Y = U'C, the same reduction over genes as (S C')
+        if (int rcy = launch_mm_reduce_kp(h, h->U, LP, h->C, (int)h->p, L, h->sc_part, h->Ylvl)) return rcy;
         NB_DISPATCH(h->NB, {
             constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
             if (ct.nitems > 0)   // no held-out entry at all: every level sum is zero
@@ -763,17 +775,9 @@ int launch_row_prep(insider_hip_handle *h, int masked)
 {
     int rc = launch_gram(h, h->C, h->p, h->CCt);
     if (rc) return rc;
-    const int KP = h->KP, LT = 256 / KP;
-    dim3 grid(h->sc_blocks, cdiv(h->SL, LT));
     // the merged update wants (S^train C'): the per-level sums of the TRAIN entries, i.e. (S C') minus sum_r bc_r
-    hipLaunchKernelGGL(k_sc_partial, grid, dim3(256), 0, h->stream,
-                       (const double *)(use_merged(h, masked) ? h->Strain : h->S), h->SL, h->SLP,
-                       (const double *)h->C, KP, (int)h->p, 256, h->sc_part);
-    KCHECK();
-    const int len = h->SL * KP;
-    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(len, 16)), dim3(256), 0, h->stream, (const double *)h->sc_part,
-                       h->sc_blocks, len, h->SC);
-    KCHECK();
+    if ((rc = launch_mm_reduce_kp(h, use_merged(h, masked) ? h->Strain : h->S, h->SLP, h->C, (int)h->p, h->SL, h->sc_part, h->SC)))
+        return rc;
     return INSIDER_OK;
 }
 

@@ -817,41 +817,6 @@ __global__ void __launch_bounds__(256) k_cont_sums(const double *__restrict__ va
     S[(size_t)g * SLP + SLcat + j] = s;
 }
 
-// Partial Gram of a tall matrix F (rows x KP): part[blk] = sum over the block's rows of f f'  (KP x KP)
-template <int KP>
-__global__ void __launch_bounds__(256) k_gram_partial(const double *__restrict__ F, int64_t rows, int rows_per_blk,
-                                                      double *__restrict__ part)
-{
-    __shared__ double s_f[64][KP + 1];
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
-    const int64_t r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
-    constexpr int PER = (KP * KP + 255) / 256;
-    double acc[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = 0.0;
-    for (int64_t rb = r0; rb < r1; rb += 64) {
-        const int nr = (int)(r1 - rb < 64 ? r1 - rb : 64);
-        __syncthreads();
-        for (int i = threadIdx.x; i < nr * KP; i += 256) s_f[i / KP][i % KP] = F[(size_t)(rb + i / KP) * KP + i % KP];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int o = threadIdx.x + 256 * i;
-            if (o < KP * KP) {
-                const int x = o / KP, y = o % KP;
-                double s = acc[i];
-                for (int r = 0; r < nr; ++r) s += s_f[r][x] * s_f[r][y];
-                acc[i] = s;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int o = threadIdx.x + 256 * i;
-        if (o < KP * KP) part[(size_t)blockIdx.x * KP * KP + o] = acc[i];
-    }
-}
-
 // out[o] = sum_b part[b][o]  (fixed order: bitwise reproducible).  Block = 16 outputs x 16 strided groups of partial
 // blocks (short dependent chains), then the 16 group sums are added in group order.
 __global__ void __launch_bounds__(256) k_sum_partials(const double *__restrict__ part, int nblk, int len,
@@ -871,63 +836,6 @@ __global__ void __launch_bounds__(256) k_sum_partials(const double *__restrict__
         for (int m = 0; m < 16; ++m) t += red[m][ol];
         out[o] = t;
     }
-}
-
-// Qfull[j][k] = sum_l Astack[l][k] * S[j][l]     (== R' x_j over all samples: x summed per level first)
-__global__ void __launch_bounds__(256) k_qfull(const double *__restrict__ S /*p x SLP*/, int SL, int SLP,
-                                               const double *__restrict__ Astack /*SL x KP*/, int KP, int p,
-                                               double *__restrict__ Q)
-{
-    constexpr int LT = 64;
-    __shared__ double s_A[LT * 64];
-    __shared__ double s_S[16 * LT];
-    const int gpb = 256 / KP;   // genes per block
-    const int k = threadIdx.x % KP, gl = threadIdx.x / KP;
-    const int j = blockIdx.x * gpb + gl;
-    const bool act = gl < gpb && j < p;
-    double acc = 0.0;
-    for (int l0 = 0; l0 < SL; l0 += LT) {
-        const int nl = SL - l0 < LT ? SL - l0 : LT;
-        __syncthreads();
-        for (int i = threadIdx.x; i < nl * KP; i += 256) s_A[i] = Astack[(size_t)l0 * KP + i];
-        for (int i = threadIdx.x; i < gpb * nl; i += 256) {
-            const int g = i / nl, l = i % nl, jj = blockIdx.x * gpb + g;
-            s_S[g * LT + l] = jj < p ? S[(size_t)jj * SLP + l0 + l] : 0.0;
-        }
-        __syncthreads();
-        if (act)
-            for (int l = 0; l < nl; ++l) acc += s_A[l * KP + k] * s_S[gl * LT + l];
-    }
-    if (act) Q[(size_t)j * KP + k] = acc;
-}
-
-// part[gb][l][k] = sum over gene block gb of S[j][l] * C[j][k]   (per-level sums of X C'); block (gb, level tile)
-__global__ void __launch_bounds__(256) k_sc_partial(const double *__restrict__ S, int SL, int SLP,
-                                                    const double *__restrict__ C, int KP, int p, int genes_per_blk,
-                                                    double *__restrict__ part)
-{
-    __shared__ double s_C[32 * 64];
-    __shared__ double s_S[32 * 16];
-    const int LT = 256 / KP;
-    const int l_loc = threadIdx.x / KP, k = threadIdx.x % KP;
-    const int l = blockIdx.y * LT + l_loc;
-    const bool act = l_loc < LT && l < SL;
-    const int j0 = blockIdx.x * genes_per_blk;
-    const int j1 = j0 + genes_per_blk < p ? j0 + genes_per_blk : p;
-    double acc = 0.0;
-    for (int jb = j0; jb < j1; jb += 32) {
-        const int ng = j1 - jb < 32 ? j1 - jb : 32;
-        __syncthreads();
-        for (int i = threadIdx.x; i < ng * KP; i += 256) s_C[i] = C[(size_t)jb * KP + i];
-        for (int i = threadIdx.x; i < ng * LT; i += 256) {
-            const int g = i / LT, ll = i % LT, lg = blockIdx.y * LT + ll;
-            s_S[g * LT + ll] = lg < SL ? S[(size_t)(jb + g) * SLP + lg] : 0.0;
-        }
-        __syncthreads();
-        if (act)
-            for (int g = 0; g < ng; ++g) acc += s_S[g * LT + l_loc] * s_C[g * KP + k];
-    }
-    if (act) part[((size_t)blockIdx.x * SL + l) * KP + k] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1382,5 +1290,6 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
 #include "insider_cd_row16.hpp"
 #include "insider_cd_reg.hpp"
 #include "insider_ridge_reg.hpp"
+#include "insider_mm.hpp"
 #include "insider_row_merged.hpp"
 #include "insider_col_factored.hpp"

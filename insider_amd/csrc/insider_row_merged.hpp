@@ -93,45 +93,8 @@ __global__ void __launch_bounds__(256) k_group_fill(const uint32_t *__restrict__
 }
 
 // ---- per outer iteration and covariate -----------------------------------------------------------------------------
-// V[j][q] = (A c_j)[q] for every stacked level q: the small product C A' (p x K times K x SL), 64 genes x 64 levels
-// per block, 4 x 4 outputs per thread, operands staged through LDS.
-// Only the stacked levels [q_begin, q_end) are (re)computed: after a covariate's update only its own columns change.
-__global__ void __launch_bounds__(256) k_gene_v(const double *__restrict__ C /*p x KP*/, const double *__restrict__ Astack
-                                                /*SL x KP*/, int p, int q_begin, int q_end, int SLP, int K, int KP,
-                                                double *__restrict__ V)
-{
-    __shared__ double s_c[64][65], s_a[64][65];   // [gene or level][k], padded: k-major reads are conflict-free
-    const int SL = q_end;
-    const int j0 = blockIdx.x * 64, q0 = q_begin + blockIdx.y * 64;
-    const int tg = threadIdx.x >> 4, tq = threadIdx.x & 15;
-    for (int i = threadIdx.x; i < 64 * KP; i += 256) {
-        const int r = i / KP, k = i % KP;
-        s_c[r][k] = j0 + r < p ? C[(size_t)(j0 + r) * KP + k] : 0.0;
-        s_a[r][k] = q0 + r < SL ? Astack[(size_t)(q0 + r) * KP + k] : 0.0;
-    }
-    __syncthreads();
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < K; ++k) {
-        double cv[4], av[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { cv[a] = s_c[tg + 16 * a][k]; av[a] = s_a[tq + 16 * a][k]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = fma(cv[a], av[b], acc[a][b]);
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int j = j0 + tg + 16 * a, q = q0 + tq + 16 * b;
-            if (j < p && q < SL) V[(size_t)j * SLP + q] = acc[a][b];
-        }
-}
+// V[j][q] = (A c_j)[q] for every stacked level q is the small product C A' (k_mm_rows, insider_mm.hpp); after a
+// covariate's update only its own columns are recomputed.
 
 // U[j][l] = sum over the held-out samples r of gene j in level l of sum_{m != cov} (A_m c_j)[level_m(r)].  One wave
 // per gene: its row of V goes to LDS; then, 64 levels at a time (their held-out samples are one contiguous range of
