@@ -173,7 +173,7 @@ def main():
                                    f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}",
                        "genes_per_gpu": p_loc, "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
                        "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"kernel": ("k_col_factored + k_qfull(held-out level sums): the column-side masked Gram/XtY complement "
+            "roofline": {"kernel": ("k_col_factored + k_mm_rows(held-out level sums x row factors): the column-side masked Gram/XtY complement "
                                     "statistics of every gene (the quantity BASELINE's metric 2 names), factored form")
                                    if prof.get("col_factored") else
                                    "k_list_stats (masked Gram/XtY complement statistics over the held-out lists, column side)",
