@@ -98,7 +98,17 @@ def _block_counts(n, p, f, seed):
         if remaining_k == 0:
             break
         good, bad = int(sizes[b]), remaining_total - int(sizes[b])
-        counts[b] = rng.hypergeometric(good, bad, remaining_k) if bad > 0 else remaining_k
+        if bad <= 0:
+            counts[b] = remaining_k
+        elif good < 10 ** 9 and bad < 10 ** 9:
+            counts[b] = rng.hypergeometric(good, bad, remaining_k)
+        else:
+            # numpy's hypergeometric refuses populations of 1e9 and more (config c4: n p = 2e9): at that size its
+            # normal limit is exact to far below one count; the sequential scheme still makes the total exactly k
+            N = good + bad
+            mean = remaining_k * good / N
+            var = remaining_k * (good / N) * (bad / N) * (N - remaining_k) / (N - 1)
+            counts[b] = int(min(max(round(rng.normal(mean, np.sqrt(var))), max(0, remaining_k - bad)), min(good, remaining_k)))
         remaining_total -= good
         remaining_k -= int(counts[b])
     return counts
