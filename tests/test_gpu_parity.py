@@ -38,6 +38,11 @@ def _need_gpu():
         pytest.fail("no HIP device visible: -m gpu tests need the MI355X box")
 
 
+# the masked statistics have two implementations each (per-entry lists / factored per level); a cost model picks one
+# per data set, so every case runs with both forced
+PATHS = {"fast": dict(row_merged=2, col_factored=2), "lists": dict(row_merged=0, col_factored=0)}
+
+
 # K + 1 <= 16 -> one MFMA block, <= 32 -> 2x2 blocks, ... : cover every block geometry and its edges
 @pytest.mark.parametrize("K", [1, 4, 15, 16, 30, 31, 32, 47, 48, 63])
 def test_masked_gram_cols_and_rows(oracle, K):
@@ -179,6 +184,29 @@ def test_ridge_column_kernel_instantiations(oracle, K, tuning):
     assert relerr(got, ref) < 1e-10, relerr(got, ref)
 
 
+@pytest.mark.parametrize("paths", ["fast", "lists"])
+@pytest.mark.parametrize("kw", [dict(level_counts=(6,), n=90, p=80, K=5),                       # a single covariate
+                                dict(level_counts=(300, 3), n=900, p=70, K=6, f=0.3),            # > 255 levels, > 64 per pass
+                                dict(level_counts=(3, 4, 2, 5, 3), n=360, p=90, K=7, f=0.2),     # five covariates
+                                dict(level_counts=(2, 2), n=40, p=300, K=18, f=0.5, with_na=True)],  # long level groups
+                         ids=["one-cov", "300-levels", "five-cov", "long-groups"])
+def test_statistics_paths_on_odd_covariate_structures(oracle, kw, paths):
+    w = workloads.small(seed=91, **kw)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    for k, v in PATHS[paths].items():
+        ds.set_option(k, v)
+    got = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=10, seed=4)
+    pr = ds.profile()
+    ds.close()
+    assert pr["row_merged"] == (paths == "fast") and pr["col_factored"] == (paths == "fast")
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                          max_iter=10, seed=4)
+    for i, a in enumerate(ref["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-8
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-8
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+
+
 def test_strong_cd_hand_kat():
     # SURVEY.md 8c item 4
     beta = api.strong_coordinate_descent(None, None, np.zeros(1), 1.0, 0.5, np.array([[2.0]]), np.array([4.0]),
@@ -207,11 +235,6 @@ CASES = {
     "k40": dict(K=40, n=150, p=60),          # K > 32: one gene per wavefront (group kernel), 3x3 MFMA blocks
     "three_cov": dict(level_counts=(4, 3, 5), n=120, p=100),
 }
-
-
-# the masked statistics have two implementations each (per-entry lists / factored per level); a cost model picks one
-# per data set, so every case runs with both forced
-PATHS = {"fast": dict(row_merged=2, col_factored=2), "lists": dict(row_merged=0, col_factored=0)}
 
 
 @pytest.mark.parametrize("paths", list(PATHS))
