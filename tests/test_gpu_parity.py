@@ -188,8 +188,10 @@ def test_ridge_column_kernel_instantiations(oracle, K, tuning):
 @pytest.mark.parametrize("kw", [dict(level_counts=(6,), n=90, p=80, K=5),                       # a single covariate
                                 dict(level_counts=(300, 3), n=900, p=70, K=6, f=0.3),            # > 255 levels, > 64 per pass
                                 dict(level_counts=(3, 4, 2, 5, 3), n=360, p=90, K=7, f=0.2),     # five covariates
-                                dict(level_counts=(2, 2), n=40, p=300, K=18, f=0.5, with_na=True)],  # long level groups
-                         ids=["one-cov", "300-levels", "five-cov", "long-groups"])
+                                dict(level_counts=(2, 2), n=40, p=300, K=18, f=0.5, with_na=True),  # long level groups
+                                # > 2048 held-out samples per gene: index staging overflows, several 512-entry tiles
+                                dict(level_counts=(5, 3), n=3000, p=24, K=4, f=0.8)],
+                         ids=["one-cov", "300-levels", "five-cov", "long-groups", "2400-held-out-per-gene"])
 def test_statistics_paths_on_odd_covariate_structures(oracle, kw, paths):
     w = workloads.small(seed=91, **kw)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
