@@ -283,10 +283,8 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
     const bool gene = j < a.p;
     __shared__ double stash[REG_STASH];
     const double *st = (a.stat && gene) ? a.stat + (size_t)j * a.stat_len : nullptr;
-    // XtX_j = R'R - complement (src/optimize.cpp:218-219), or the shared R'R (:234); zero diagonal in registers.
-    // Branch-free: without statistics the subtrahend is read from R'R itself (any valid memory) and scaled by 0.
-    const double *stp = st ? st : a.RtR;
-    const double ms = st ? 1.0 : 0.0;
+    // XtX_j = R'R - complement (src/optimize.cpp:218-219: the statistics record holds it ready-made), or the shared R'R
+    // (:234); zero diagonal in registers.  One operand stream per element: two would make the allocator spill the matrix.
     double G[SLOTS][KMAX], q[SLOTS], Gll[SLOTS], beta[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
@@ -299,14 +297,13 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
             const int bk = k >> 4;
             const int si = bk >= u ? (bk * (bk + 1) / 2 + u) * 256 + (k & 15) * 16 + i
                                    : (u * (u + 1) / 2 + bk) * 256 + i * 16 + (k & 15);
-            const double v = fma(-ms, stp[si], a.RtR[k * KP + c]);
+            const double v = st ? st[si] : a.RtR[k * KP + c];
             G[u][k] = (ok && k < K && k != c) ? v : 0.0;
         }
         q[u] = 0.0;
         beta[u] = 0.0;
         if (ok) {
-            Gll[u] = a.RtR[c * KP + c];
-            if (st) Gll[u] -= st[stat_index(c, c)];
+            Gll[u] = st ? st[stat_index(c, c)] : a.RtR[c * KP + c];
             q[u] = a.Qfull[(size_t)j * KP + c];                                          // :222,235 via level sums
             if (st) q[u] -= st[stat_index(KP - 1, c)];                                   // minus the held-out part
             beta[u] = a.C[(size_t)j * KP + c];

@@ -285,8 +285,7 @@ __global__ void __launch_bounds__(64) k_cd_cols_r16(ColArgs a)
         for (int k = 0; k < K; ++k) {
             double v = 0.0;
             if (ok) {
-                v = a.RtR[k * KP + c];
-                if (st) v -= st[stat_index(k, c)];
+                v = st ? st[stat_index(k, c)] : a.RtR[k * KP + c];
             }
             if (k == c) { Gll[u] = ok ? v : 1.0; v = 0.0; }
             if (c < K) Gg[k * K + c] = v;

@@ -10,8 +10,8 @@
 // held-out entries — and every held-out entry costs one K-vector add of a row of a SMALL table (the covariates after
 // the first have few levels; their rows live in LDS).  The x-dependent statistics need no pass at all:
 //   qc_j = sum_{i in H(j)} x_ij r_i = sum_l A_l' (S - S^train)[j][l],    sum_{H(j)} x^2 = yy_all - yy_train.
-// Output: the same block layout as k_list_stats (lower 16x16 blocks of the (KP x KP) matrix with qc in row KP-1 and the
-// sum of squares in its corner), so the solve kernels do not change.  The level-grouped entry lists are those of the
+// Output: the same record as k_list_stats with base = R'R (lower 16x16 blocks: XtX_j = R'R - Gc in the K x K part, qc in
+// row KP-1 and the sum of squares in its corner), so the solve kernels do not change.  The level-grouped entry lists are those of the
 // merged row update (insider_row_merged.hpp).
 #pragma once
 
@@ -32,6 +32,7 @@ struct ColFacArgs {
     int tab_rows;                         // SLcat - tab_skip_n
     const double *Astack;                 // SLcat x KP
     const double *Qheld;                  // p x KP: sum_l A_l' (S - S^train)[j][l]
+    const double *RtR;                    // KP x KP: the record's K x K part is R'R - Gc = XtX_j (see k_list_stats)
     const double *yy_all, *yy_train;
     double *stat;                         // [p][STAT]
 };
@@ -144,7 +145,11 @@ __global__ void __launch_bounds__(WPB * 64) k_col_factored(ColFacArgs a)
             wave_sync();
             d4 res;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) res[r] = acc[bi][bj][r] + tr[c16 * 17 + g4 + 4 * r];
+            for (int r = 0; r < 4; ++r) {
+                const int ra = 16 * bi + g4 + 4 * r, cb = 16 * bj + c16;
+                res[r] = acc[bi][bj][r] + tr[c16 * 17 + g4 + 4 * r];
+                if (ra < a.K && cb < a.K) res[r] = a.RtR[ra * KP + cb] - res[r];
+            }
             wave_sync();
             if (bi == NB - 1 && g4 == 3) {   // global row KP - 1 = local row 15 = register 3 of lanes 48..63
                 const int col = 16 * bj + c16;

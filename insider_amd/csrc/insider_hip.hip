@@ -262,7 +262,8 @@ int ensure_workspace(insider_hip_handle *h, int K)
         default: { constexpr int NB_ = 4; constexpr int WPB_ = 1; __VA_ARGS__; } break;  \
     }
 
-int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *F, double *stat)
+int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *F, double *stat,
+                      const double *base = nullptr)
 {
     const int units = cols ? (int)h->p : (int)h->n;
     const int64_t f_rows = cols ? h->n : h->p;
@@ -271,7 +272,7 @@ int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *
     const double *lval = cols ? h->col_val : h->row_val;
     const int64_t items = (int64_t)units * nseg;
     NB_DISPATCH(h->NB, hipLaunchKernelGGL((k_list_stats<NB_, WPB_>), dim3(cdiv(items, WPB_)), dim3(WPB_ * 64), 0,
-                                           h->stream, ptr, lidx, lval, units, nseg, F, f_rows, stat));
+                                           h->stream, ptr, lidx, lval, units, nseg, F, f_rows, stat, base, h->K));
     KCHECK();
     return INSIDER_OK;
 }
@@ -397,6 +398,7 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
         a.K = h->K;
         a.Astack = h->Astack;
         a.Qheld = h->Qheld;
+        a.RtR = h->RtR;
         a.yy_all = h->yy_all;
         a.yy_train = h->yy_train;
         a.stat = h->stat_col;
@@ -407,7 +409,7 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
         });
         KCHECK();
     } else {
-        rc = launch_list_stats(h, true, 1, h->R, h->stat_col);
+        rc = launch_list_stats(h, true, 1, h->R, h->stat_col, h->RtR);   // the record's K x K part = R'R - complement
         if (rc) return rc;
     }
     return t.end(h, h->ev_col);

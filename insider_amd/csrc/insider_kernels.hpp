@@ -454,7 +454,8 @@ __device__ __forceinline__ bool gj_solve_regs(double (&row)[KP], int K, double &
 template <int NB, int WPB>
 __global__ void __launch_bounds__(WPB * 64)
 k_list_stats(const uint32_t *__restrict__ ptr, const int *__restrict__ lidx, const double *__restrict__ lval, int units,
-             int nseg, const double *__restrict__ F, int64_t f_rows, double *__restrict__ stat)
+             int nseg, const double *__restrict__ F, int64_t f_rows, double *__restrict__ stat,
+             const double *__restrict__ base /*KP x KP or null*/, int K)
 {
     constexpr int NBLK = Geo<NB>::NBLK;
     __shared__ int s_li[WPB][2][LIST_BLOCK];
@@ -506,12 +507,23 @@ k_list_stats(const uint32_t *__restrict__ ptr, const int *__restrict__ lidx, con
             drain_syrk<NB>(li, lx, left < LIST_BLOCK / SYRK_BATCH ? left : LIST_BLOCK / SYRK_BATCH, rsrc, acc, lane);
         }
     }
+    // With `base` (column side of the solver: base = R'R) the K x K part of the record is base - complement, i.e. the
+    // gene's XtX itself (src/optimize.cpp:218-219): the solve kernels then read ONE operand stream per element.  Row
+    // KP - 1 (the x slot) keeps the complement sums.
     double *out = stat + (size_t)item * Geo<NB>::STAT;
     const int sub = lane >> 4, c16 = lane & 15;
+    int blk = 0;
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b)
+    for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[b * 256 + (sub + 4 * r) * 16 + c16] = acc[b][r];
+        for (int bj = 0; bj <= bi; ++bj, ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ra = 16 * bi + sub + 4 * r, cb = 16 * bj + c16;
+                double v = acc[blk][r];
+                if (base && ra < K && cb < K) v = base[ra * Geo<NB>::KP + cb] - v;
+                out[blk * 256 + (sub + 4 * r) * 16 + c16] = v;
+            }
 }
 
 // ---- building the lists (once per data set) -----------------------------------------------------------------
@@ -608,8 +620,7 @@ __global__ void __launch_bounds__(WPB * 64) k_cd_cols(ColArgs a)
     for (int k = 0; k < K; ++k) {
         double v = 0.0;
         if (valid) {
-            v = a.RtR[k * KP + l];
-            if (st) v -= st[stat_index(k, l)];
+            v = st ? st[stat_index(k, l)] : a.RtR[k * KP + l];   // the record holds XtX_j itself (see k_list_stats)
         }
         if (k == l) { Gll = valid ? v : 1.0; v = 0.0; }
         Goff[k * W + l] = v;
@@ -686,7 +697,7 @@ __global__ void __launch_bounds__(WPB * 64) k_ridge_cols(RidgeArgs a)
     const double *st = a.stat ? a.stat + (size_t)j * a.stat_len : nullptr;
     auto load = [&]() {
         for (int k = 0; k < K; ++k)
-            if (valid) A[k * K + lane] = a.RtR[k * KP + lane] - (st ? st[stat_index(k, lane)] : 0.0);
+            if (valid) A[k * K + lane] = st ? st[stat_index(k, lane)] : a.RtR[k * KP + lane];
         wave_sync();
     };
     load();

@@ -83,8 +83,6 @@ __device__ __forceinline__ bool ridge_solve_regs(double (&G)[SLOTS][KMAX], doubl
 template <int SLOTS, int KMAX>
 __device__ __forceinline__ void ridge_load(const RidgeArgs &a, const double *st, bool gene, int i, double (&G)[SLOTS][KMAX])
 {
-    const double *stp = st ? st : a.RtR;                  // branch-free: without statistics subtract 0 x (valid memory)
-    const double ms = st ? 1.0 : 0.0;
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         const int c = 16 * u + i;
@@ -94,7 +92,7 @@ __device__ __forceinline__ void ridge_load(const RidgeArgs &a, const double *st,
             const int bk = k >> 4;
             const int si = bk >= u ? (bk * (bk + 1) / 2 + u) * 256 + (k & 15) * 16 + i
                                    : (u * (u + 1) / 2 + bk) * 256 + i * 16 + (k & 15);
-            const double v = fma(-ms, stp[si], a.RtR[k * a.KP + c]);
+            const double v = st ? st[si] : a.RtR[k * a.KP + c];   // the record holds XtX_j itself
             G[u][k] = (okc && k < a.K) ? v : 0.0;
         }
     }
