@@ -118,6 +118,7 @@ struct insider_hip_handle {
     int row_merged = 1;               // option: use it
     double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
     int *sweeps = nullptr, *failflag = nullptr;
+    int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sweep_key)
     unsigned long long *sweep_total = nullptr;
     uint8_t *order = nullptr;
     int order_rows = 0;
@@ -156,6 +157,8 @@ void free_workspace(insider_hip_handle *h)
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->sweeps) (void)hipFree(h->sweeps);
+    if (h->sweep_key) (void)hipFree(h->sweep_key);
+    h->sweep_key = nullptr;
     if (h->failflag) (void)hipFree(h->failflag);
     if (h->sweep_total) (void)hipFree(h->sweep_total);
     if (h->order) (void)hipFree(h->order);
@@ -231,6 +234,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->gene_ids, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sweeps_sorted, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->sweep_key, (size_t)h->p))) return rc;
     for (int e = 0; e < insider_hip_handle::EARLY; ++e)
         if ((rc = dmalloc(&h->perm_early[e], (size_t)h->p))) return rc;
     {
@@ -497,7 +501,10 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
     if (solve && alpha != 0.0) {
         // schedule the next solve longest-first, genes of similar length sharing a wave (stable sort: deterministic)
         size_t bytes = h->sort_tmp_bytes;
-        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweeps, h->sweeps_sorted,
+        hipLaunchKernelGGL(k_sweep_key, dim3(cdiv(h->p, 256)), dim3(256), 0, h->stream, (const int *)h->sweeps, (int)h->p,
+                           (outer_iter < insider_hip_handle::EARLY || !h->have_perm) ? 1 : 0, h->sweep_key);
+        KCHECK();
+        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweep_key, h->sweeps_sorted,
                                                               h->gene_ids, h->gene_perm, (int)h->p, 0, 32, h->stream));
         h->have_perm = true;
         if (early) {
