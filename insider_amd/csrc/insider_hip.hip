@@ -1224,7 +1224,6 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     if ((rc = ensure_workspace(h, K))) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     clear_events(h);
-    const int KP = h->KP;
     const int masked = tuning == 1;
     if ((rc = upload_factors(h, A, C, K))) return rc;
 
