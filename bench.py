@@ -7,8 +7,12 @@ A "step" is one outer iteration of the reference's optimize() (src/optimize.cpp:
 updates, the column update and the amortised checkpoint work.  The timed region is ONE optimize() call of K outer
 iterations (max_iter = K-1; K = 31 is exactly a tuning_iter = 30 call of tune(), R/insider.R:163-164) with X, the
 masks and the level tables already resident in HBM; W warm-up iterations run first through a separate call.
-N > 1: one process per GPU (torchrun), genes sharded across ranks (strong scaling: the total workload is fixed),
-RCCL all-reduces of the per-level normal equations and of the loss terms.
+N > 1: one process per GPU (torchrun), genes sharded across ranks, RCCL all-reduces of the per-level normal equations
+and of the loss terms.  --scaling weak (default): every GPU holds one slab of the workload's own gene count, i.e. the
+problem is n x (p N) (N = 4 on c3 is exactly BASELINE's config c4, 10000 x 200000) and `value` = N x outer
+iterations/s of that problem (slab-iterations per second, so value(N) / (N value(1)) is the scaling efficiency).
+--scaling strong: the workload's own p genes are split N ways (c3 / 8 = 6250 genes per GPU is fewer than the 12288
+the sweep kernel needs to fill one MI355X).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the column-side masked Gram/XtY statistics (the quantity
 BASELINE.json's metric names), timed live with HIP events on the library's stream; `cd_kernel` reports the
@@ -36,6 +40,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=31)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = one slab of the workload's gene count per GPU (p N genes in all); strong = p genes split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-genes", type=int, default=0, help="0 = choose for ~10-30 s of CPU work")
     ap.add_argument("--seed", type=int, default=20240301)
@@ -95,10 +101,18 @@ def main():
             sys.exit(2)
     import torch
     import torch.distributed as dist
+    # rehearsal of the N > 1 path on a one-GPU box: every rank on GPU 0, all-reduces staged through the host over gloo
+    # (RCCL refuses two ranks on one device); the timing is then not a scaling measurement
+    one_gpu = world > 1 and os.environ.get("INSIDER_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
@@ -108,14 +122,17 @@ def main():
 
     name = args.workload
     n, p_total, _, _, K, lam, alpha, tuning, f = workloads.CONFIGS[name]
+    weak = args.scaling == "weak"
+    slabs = world if weak else 1          # weak scaling: the problem grows with the GPU count
+    p_total *= slabs
     lo, hi = idist.shard_range(p_total, rank, world)
     t0 = time.perf_counter()
-    w = workloads.make(name, gene_range=(lo, hi))
+    w = workloads.make(name, p=p_total, gene_range=(lo, hi))
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, device=local_rank)
     t_up = time.perf_counter() - t0
-    idist.attach(ds, lo, rank, world, device=local_rank)
+    idist.attach(ds, lo, rank, world, device=local_rank, staged=one_gpu)
     ds.set_option("profile", 1)
     p_loc = hi - lo
 
@@ -142,7 +159,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ds.profile()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert res["iters"] == args.steps, (res["iters"], args.steps)
@@ -166,13 +183,17 @@ def main():
         out = {
             "metric": "outer-iterations/sec (masked INSIDER fit, 10k x 50k, K=30)" if name == "c3" else
                       f"outer-iterations/sec ({name})",
-            "value": args.steps / dt, "unit": "outer-iterations/s", "n_gpus": world, "steps": args.steps,
+            "value": slabs * args.steps / dt, "unit": "outer-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}: {n}x{p_total} fp64, K={K}, lambda={lam}, alpha={alpha}, "
                                    f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}",
-                       "genes_per_gpu": p_loc, "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
-                       "parallelism": f"gene-shard x{world}" if world > 1 else "single GPU"},
+                       "genes_per_gpu": p_loc, "problem_iterations_per_s": args.steps / dt,
+                       "value_is": (f"{slabs} x outer iterations/s of the {n}x{p_total} problem (one {name}-sized gene slab per GPU)"
+                                    if slabs > 1 else "outer iterations/s"),
+                       "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
+                       "parallelism": (f"gene-shard x{world}" + (" (REHEARSAL: all ranks on one GPU, host-staged all-reduce)" if one_gpu else ""))
+                                      if world > 1 else "single GPU"},
             "roofline": {"kernel": ("k_col_factored + k_mm_rows(held-out level sums x row factors): the column-side masked Gram/XtY complement "
                                     "statistics of every gene (the quantity BASELINE's metric 2 names), factored form")
                                    if prof.get("col_factored") else
@@ -200,7 +221,7 @@ def main():
             "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"],
             "setup_s": {"generate": t_gen, "upload_and_precompute": t_up},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is an N = 1 figure
             try:
                 out["cpu_baseline"] = cpu_baseline(name, lam, alpha, host_cores(),
                                                    out["cd_kernel"]["sweeps_per_gene_per_iter"])
