@@ -161,7 +161,8 @@ class InsiderData:
         return dict(col_stats_launches=int(out[0]), col_stats_ms=out[1], row_stats_launches=int(out[2]),
                     row_stats_ms=out[3], cd_launches=int(out[4]), cd_ms=out[5], test_launches=int(out[6]),
                     test_ms=out[7], wall_ms=out[8], iters=int(out[9]), sweeps=int(out[10]),
-                    col_factored=bool(int(out[11]) & 1), row_merged=bool(int(out[11]) & 2))
+                    col_factored=bool(int(out[11]) & 1), row_merged=bool(int(out[11]) & 2),
+                    col_pair=bool(int(out[11]) & 4))
 
     def sweeps(self):
         """Per-gene sweep counts of the last column update."""

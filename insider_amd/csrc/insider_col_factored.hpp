@@ -19,6 +19,8 @@ namespace insider {
 
 constexpr int CF_MAXC = 8;        // covariates
 constexpr int CF_CAP = 2048;      // uint16 look-up indices staged per wave (entries x later covariates)
+constexpr int CP_MAXSTEPS = 8;    // pair-count form: table rows / 4 (k-steps of the count product)
+constexpr int CP_MAXCELLS = 4096; // pair-count form: count bytes one pass of the builder histograms in LDS
 
 struct ColFacArgs {
     int p, K, c;
@@ -35,7 +37,47 @@ struct ColFacArgs {
     const double *RtR;                    // KP x KP: the record's K x K part is R'R - Gc = XtX_j (see k_list_stats)
     const double *yy_all, *yy_train;
     double *stat;                         // [p][STAT]
+    // pair-count form (k_col_paircnt): per gene and position t the dense counts n_j(l, q) of held-out entries in level
+    // l of the covariate at t whose LATER covariate has table row q, one byte per cell, stored in MFMA A-operand order
+    // [l / 16][lane = (q % 4) * 16 + l % 16][q / 4] with 4 or 8 bytes per lane (one dword / two dwords per lane and
+    // block of 16 levels); static per data set (mask and levels only)
+    const uint8_t *cnt;
+    int cnt_stride, cnt_off[CF_MAXC], nsteps;   // bytes per gene, offset of position t, ceil(tab_rows / 4)
 };
+
+// Gc = M + M' for the lower blocks, XtX_j = R'R - Gc; qc and the sum of squares go into row KP - 1 of the record
+template <int NB>
+__device__ __forceinline__ void cf_store(d4 (&acc)[NB][NB], double *tr, const ColFacArgs &a, int j, int lane)
+{
+    constexpr int KP = Geo<NB>::KP;
+    const int g4 = lane >> 4, c16 = lane & 15;
+    double *out = a.stat + (size_t)j * Geo<NB>::STAT;
+    const double ss = a.yy_all[j] - a.yy_train[j];
+    int blk = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj, ++blk) {
+            // transpose M(bj, bi) through LDS: register r of lane l holds element ((l >> 4) + 4 r, l & 15)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tr[(g4 + 4 * r) * 17 + c16] = acc[bj][bi][r];
+            wave_sync();
+            d4 res;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ra = 16 * bi + g4 + 4 * r, cb = 16 * bj + c16;
+                res[r] = acc[bi][bj][r] + tr[c16 * 17 + g4 + 4 * r];
+                if (ra < a.K && cb < a.K) res[r] = a.RtR[ra * KP + cb] - res[r];
+            }
+            wave_sync();
+            if (bi == NB - 1 && g4 == 3) {   // global row KP - 1 = local row 15 = register 3 of lanes 48..63
+                const int col = 16 * bj + c16;
+                res[3] = col < a.K ? a.Qheld[(size_t)j * KP + col] : (col == KP - 1 ? ss : 0.0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[blk * 256 + (g4 + 4 * r) * 16 + c16] = res[r];
+        }
+}
 
 template <int NB, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_col_factored(ColFacArgs a)
@@ -131,34 +173,162 @@ __global__ void __launch_bounds__(WPB * 64) k_col_factored(ColFacArgs a)
         }
         wave_sync();
     }
-    // ---- Gc = M + M' for the lower blocks; qc and the sum of squares go into row KP - 1 ---------------------------
-    double *out = a.stat + (size_t)j * Geo<NB>::STAT;
-    const double ss = a.yy_all[j] - a.yy_train[j];
-    int blk = 0;
+    cf_store<NB>(acc, tr, a, j, lane);
+    (void)NBLK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair-count form of the same statistics: p_jl = 1/2 n_jl a_l + sum_q n_j(l, q) tab_q, i.e. P = 1/2 diag(n) A + N_j Tab
+// with the DENSE count matrix N_j (levels of the covariate x rows of the table of the later covariates).  N_j depends
+// on the mask and the level ids only: it is built once per data set (k_pair_count_build), and the per-entry work of
+// k_col_factored (one LDS row read + K-vector add per held-out entry) becomes ceil(L / 16) x ceil(rows / 4) x NB MFMAs.
+// Worth it when the cells are not many more than the entries (c3: 100 x 10 cells for ~1000 entries per gene).
+// One wave per gene.  16 levels at a time: P (16 x KP) = N_j-block x Tab by MFMA, + 1/2 n a in the accumulator layout
+// (register r of lane (g4, c16) holds level g4 + 4 r — exactly the level that k-step r of the second product needs
+// from that lane, so P feeds M += A' P with no data movement).
+template <int NB>
+struct PairBlk {          // operands of one block of 16 levels, raw as fetched (nothing here waits for the loads)
+    uint32_t cw[2];       // this lane's count bytes (k-step s = byte s)
+    double av[4][NB];     // factor rows: k-step s holds level min(l0 + 4 s + g4, L - 1), component 16 bb + c16
+    uint32_t gb[4], ge[4];   // group bounds of those levels
+};
+
+template <int NB, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
+{
+    constexpr int KP = Geo<NB>::KP;
+    extern __shared__ double s_cp[];   // per wave: 16 x 17 transpose scratch | table rows [4 nsteps][KP], zero padded
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *tr = s_cp + (size_t)w * 16 * 17;
+    double *tabs = s_cp + (size_t)WPB * 16 * 17;
+    for (int i = threadIdx.x; i < 4 * a.nsteps * KP; i += WPB * 64) {
+        const int r = i / KP, k = i % KP;
+        const int q = r < a.tab_skip_lo ? r : r + a.tab_skip_n;
+        tabs[i] = r < a.tab_rows ? a.Astack[(size_t)q * KP + k] : 0.0;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * WPB + w;
+    if (j >= a.p) return;
+    const int g4 = lane >> 4, c16 = lane & 15;
+    const int bpl = a.nsteps <= 4 ? 4 : 8;   // count bytes per lane and block
+    const double *tbl = tabs + g4 * KP + c16;   // B operand of k-step s, block bb: tbl[4 s KP + 16 bb]
+    d4 acc[NB][NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-        for (int bj = 0; bj <= bi; ++bj, ++blk) {
-            // transpose M(bj, bi) through LDS: register r of lane l holds element ((l >> 4) + 4 r, l & 15)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tr[(g4 + 4 * r) * 17 + c16] = acc[bj][bi][r];
-            wave_sync();
-            d4 res;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ra = 16 * bi + g4 + 4 * r, cb = 16 * bj + c16;
-                res[r] = acc[bi][bj][r] + tr[c16 * 17 + g4 + 4 * r];
-                if (ra < a.K && cb < a.K) res[r] = a.RtR[ra * KP + cb] - res[r];
+        for (int bj = 0; bj < NB; ++bj) acc[bi][bj] = d4{0.0, 0.0, 0.0, 0.0};
+    const uint8_t *cj = a.cnt + (size_t)j * a.cnt_stride;
+    for (int t = 0; t < a.c; ++t) {
+        const uint32_t *g = a.grp[t] + (size_t)j * (a.L[t] + 1);
+        const int Lo = a.L[t];
+        const bool cross = a.nlater[t] > 0;   // wave-uniform
+        const uint8_t *ct = cj + a.cnt_off[t];
+        const double *At = a.Astack + (size_t)a.off[t] * KP + c16;
+        // every load is unconditional (clamped index, zero weight): conditional loads would be serialised by branches
+        auto fetch = [&](int l0, PairBlk<NB> &b) {
+            b.cw[0] = b.cw[1] = 0;
+            if (cross) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)(l0 >> 4) * 64 + lane) * bpl);
+                b.cw[0] = src[0];
+                if (bpl == 8) b.cw[1] = src[1];
             }
-            wave_sync();
-            if (bi == NB - 1 && g4 == 3) {   // global row KP - 1 = local row 15 = register 3 of lanes 48..63
-                const int col = 16 * bj + c16;
-                res[3] = col < a.K ? a.Qheld[(size_t)j * KP + col] : (col == KP - 1 ? ss : 0.0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int l = l0 + 4 * s + g4;
+                const int lc = l < Lo ? l : Lo - 1;
+                b.gb[s] = g[lc];
+                b.ge[s] = g[lc + 1];
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) b.av[s][bb] = At[(size_t)lc * KP + 16 * bb];
+            }
+        };
+        for (int l0 = 0; l0 < Lo; l0 += 16) {
+            PairBlk<NB> cur;
+            fetch(l0, cur);
+            double hn[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {            // levels beyond the last: zero weight
+                const double keep = l0 + 4 * s + g4 < Lo ? 1.0 : 0.0;
+                hn[s] = keep * 0.5 * (double)(cur.ge[s] - cur.gb[s]);
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) cur.av[s][bb] *= keep;
+            }
+            d4 P[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) P[bb] = d4{0.0, 0.0, 0.0, 0.0};
+            if (cross) {
+#pragma unroll
+                for (int s = 0; s < CP_MAXSTEPS; ++s)
+                    if (s < a.nsteps) {   // wave-uniform
+                        const double cv = (double)((cur.cw[s >> 2] >> (8 * (s & 3))) & 0xffu);
+#pragma unroll
+                        for (int bb = 0; bb < NB; ++bb)
+                            P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv, tbl[4 * s * KP + 16 * bb], P[bb], 0, 0, 0);
+                    }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[blk * 256 + (g4 + 4 * r) * 16 + c16] = res[r];
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) P[bb][s] = fma(hn[s], cur.av[s][bb], P[bb][s]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (l0 + 4 * s < Lo) {   // wave-uniform
+#pragma unroll
+                    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                        for (int bj = 0; bj < NB; ++bj)
+                            acc[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[s][bi], P[bj][s], acc[bi][bj], 0, 0, 0);
+                }
         }
-    (void)NBLK;
+    }
+    cf_store<NB>(acc, tr, a, j, lane);
+}
+
+// The dense pair counts of every gene (once per data set): one wave per gene, LDS histogram per covariate position.
+// overflow: set when a cell exceeds one byte (the pair-count form is then not used).
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_pair_count_build(ColFacArgs a, uint8_t *cnt, int *overflow)
+{
+    __shared__ uint32_t hist[WPB][CP_MAXCELLS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * WPB + w;
+    if (j >= a.p) return;
+    uint32_t *hw = hist[w];
+    const int bpl = a.nsteps <= 4 ? 4 : 8;
+    const int pass_levels = CP_MAXCELLS / (64 * bpl) * 16;   // levels whose cells fit the histogram
+    for (int t = 0; t < a.c; ++t) {
+        const int Lo = a.L[t], nl = a.nlater[t];
+        if (nl == 0) continue;
+        const uint32_t *g = a.grp[t] + (size_t)j * (Lo + 1);
+        for (int lb = 0; lb < Lo; lb += pass_levels) {
+            const int le = lb + pass_levels < Lo ? lb + pass_levels : Lo;
+            const int cells = ((le - lb + 15) >> 4) * 64 * bpl;
+            for (int i = lane; i < cells; i += WAVE) hw[i] = 0;
+            wave_sync();
+            for (int l = lb; l < le; ++l) {
+                const uint32_t b = g[l], e = g[l + 1];
+                const int ll = l - lb;
+                for (int k = 0; k < nl; ++k) {
+                    const uint16_t *src = a.slev[t] + (size_t)a.later_plane[t][k] * a.plane;
+                    for (uint32_t x = b + lane; x < e; x += WAVE) {
+                        int q = (int)src[x];
+                        q = q < a.tab_skip_lo ? q : q - a.tab_skip_n;
+                        atomicAdd(&hw[(((ll >> 4) * 64) + (q & 3) * 16 + (ll & 15)) * bpl + (q >> 2)], 1u);
+                    }
+                }
+            }
+            wave_sync();
+            uint8_t *out = cnt + (size_t)j * a.cnt_stride + a.cnt_off[t] + (size_t)(lb >> 4) * 64 * bpl;
+            bool big = false;
+            for (int i = lane; i < cells; i += WAVE) {
+                const uint32_t v = hw[i];
+                big = big || v > 255u;
+                out[i] = (uint8_t)(v > 255u ? 255u : v);
+            }
+            if (big) *overflow = 1;
+            wave_sync();
+        }
+    }
 }
 
 // Sheld = S - Strain (once per data set)

@@ -109,7 +109,9 @@ struct insider_hip_handle {
     double *Strain = nullptr;         // per-level sums of X over TRAIN entries (p x SLP), once per data set
     double *Sheld = nullptr;          // S - Strain: per-level sums over the held-out entries
     double *Qheld = nullptr;          // p x KP workspace: sum_l A_l' Sheld[j][l]
-    int col_factored = 1;             // option: factored column statistics (insider_col_factored.hpp)
+    int col_factored = 1;             // option: factored column statistics (insider_col_factored.hpp): 0 list kernel, 1 cost model, 2 look-up form, 3 pair-count form
+    uint8_t *cf_cnt = nullptr;        // dense pair counts of every gene (pair-count form), static per data set
+    bool cf_pair_ok = false;
     ColFacArgs cf;                    // its static part (filled at create)
     size_t cf_lds = 0;
     double *U = nullptr, *Ylvl = nullptr, *wpart = nullptr, *Vlev = nullptr;   // merged row update workspace
@@ -370,25 +372,36 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     return INSIDER_OK;
 }
 
-// factored column statistics available and worth it?  (LDS: the table of the covariates after the largest one.)  Issue-cycle
-// model per gene with E held-out entries: the list kernel spends NBLK MFMAs (64 cycles) per 4 entries; the factored one
-// NB^2 MFMAs per 4 levels plus, per later covariate and 16-entry batch of a level group, 16 x (2 + NB) vector
-// instructions (4.6 cycles).  Measured at c3 / c5: 0.51 vs 1.30 ms (model 14.5k vs 48k cycles) and 2.44 vs 0.66 ms (72k vs 24k).
-bool use_col_factored(const insider_hip_handle *h)
+// Which kernel forms the column-side statistics: 0 = k_list_stats (one rank-one MFMA group per held-out entry), 1 =
+// k_col_factored (look-up form), 2 = k_col_paircnt (pair-count form).  Issue-cycle models per gene with E held-out
+// entries: the list kernel spends NBLK MFMAs (64 cycles) per 4 entries; the look-up form NB^2 MFMAs per 4 levels plus, per
+// later covariate and 16-entry batch of a level group, 16 x (2 + NB) vector instructions (4.6 cycles); the pair-count form
+// NB^2 MFMAs per 4 levels plus ceil(rows / 4) x NB MFMAs per 16 levels.  Measured at c3 / c5: look-up 0.51 vs list 1.30 ms
+// (model 14.5k vs 48k cycles) and 2.44 vs 0.66 ms (72k vs 24k).
+int col_stats_path(const insider_hip_handle *h)
 {
-    if (!(h->merged && h->col_factored && h->m == 0 && h->c <= CF_MAXC)) return false;
-    if (((size_t)(h->cf.tab_rows + 1) * h->KP + 4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2 > 64 * 1024) return false;
-    if (h->col_factored == 2) return true;   // forced
+    if (!(h->merged && h->col_factored && h->m == 0 && h->c <= CF_MAXC)) return 0;
+    const bool lookup_fits =
+        ((size_t)(h->cf.tab_rows + 1) * h->KP + 4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2 <= 64 * 1024;
+    if (h->col_factored == 3 && h->cf_pair_ok) return 2;                   // forced
+    if (h->col_factored >= 2) return lookup_fits ? 1 : (h->cf_pair_ok ? 2 : 0);   // forced (3 without a count table: look-up form)
     const double E = (double)h->col_entries / (double)std::max<int64_t>(h->p, 1);
     const int NB = h->NB;
     const double list = E * (NB * (NB + 1) / 2) * 16.0;
-    double fac = 0.0;
+    double fac = 0.0, pair = 0.0;
     for (int t = 0; t < h->cf.c; ++t) {
         const double batches = std::ceil(std::max(1.0, E / h->cf.L[t]) / 16.0);
         fac += std::ceil(h->cf.L[t] / 4.0) * (NB * NB * 64.0 + h->cf.nlater[t] * batches * 16.0 * (2 + NB) * 4.6);
+        pair += std::ceil(h->cf.L[t] / 4.0) * NB * NB * 64.0 +
+                std::ceil(h->cf.L[t] / 16.0) * ((h->cf.nlater[t] > 0 ? h->cf.nsteps * NB * 64.0 : 0.0) + 150.0);
     }
-    return 1.3 * fac < list;
+    double best = list;
+    int path = 0;
+    if (lookup_fits && 1.3 * fac < best) { best = 1.3 * fac; path = 1; }
+    if (h->cf_pair_ok && 1.3 * pair < best) { best = 1.3 * pair; path = 2; }
+    return path;
 }
+bool use_col_factored(const insider_hip_handle *h) { return col_stats_path(h) != 0; }
 
 // masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
 int launch_col_stats(insider_hip_handle *h, bool timed)
@@ -406,11 +419,20 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
         a.yy_all = h->yy_all;
         a.yy_train = h->yy_train;
         a.stat = h->stat_col;
-        NB_DISPATCH(h->NB, {
-            (void)WPB_;
-            const size_t lds = ((size_t)(a.tab_rows + 1) * Geo<NB_>::KP + (size_t)4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2;
-            hipLaunchKernelGGL((k_col_factored<NB_, 4>), dim3(cdiv(h->p, 4)), dim3(256), lds, h->stream, a);
-        });
+        if (col_stats_path(h) == 2) {
+            a.cnt = h->cf_cnt;
+            NB_DISPATCH(h->NB, {
+                (void)WPB_;
+                const size_t lds = ((size_t)4 * 16 * 17 + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
+                hipLaunchKernelGGL((k_col_paircnt<NB_, 4>), dim3(cdiv(h->p, 4)), dim3(256), lds, h->stream, a);
+            });
+        } else {
+            NB_DISPATCH(h->NB, {
+                (void)WPB_;
+                const size_t lds = ((size_t)(a.tab_rows + 1) * Geo<NB_>::KP + (size_t)4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2;
+                hipLaunchKernelGGL((k_col_factored<NB_, 4>), dim3(cdiv(h->p, 4)), dim3(256), lds, h->stream, a);
+            });
+        }
         KCHECK();
     } else {
         rc = launch_list_stats(h, true, 1, h->R, h->stat_col, h->RtR);   // the record's K x K part = R'R - complement
@@ -846,6 +868,7 @@ void insider_hip_destroy(insider_hip_handle *h)
     }
     if (h->Strain) (void)hipFree(h->Strain);
     if (h->Sheld) (void)hipFree(h->Sheld);
+    if (h->cf_cnt) (void)hipFree(h->cf_cnt);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1171,6 +1194,33 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
             cf.tab_skip_lo = h->lvl_off[ord[0]];
             cf.tab_skip_n = n_levels[ord[0]];
             cf.tab_rows = h->SLcat - cf.tab_skip_n;
+            // pair-count form: the dense per-gene count tables (one byte per cell), when they are small enough
+            cf.nsteps = (cf.tab_rows + 3) / 4;
+            bool fits = cf.nsteps <= CP_MAXSTEPS;
+            int off = 0;
+            for (int t = 0; t < c; ++t) {
+                const int cells = ((cf.L[t] + 15) / 16) * 64 * (cf.nsteps <= 4 ? 4 : 8);   // bytes: 4 or 8 per lane and block
+                cf.cnt_off[t] = off;
+                if (cf.nlater[t] > 0) off += cells;
+            }
+            cf.cnt_stride = off;
+            cf.cnt = nullptr;
+            if (fits && off <= 64 * 1024 && (size_t)p * (size_t)off <= ((size_t)1 << 32)) {   // <= 64 KB of counts per gene
+                int *ovf = nullptr;
+                if (off > 0) {
+                    CR(dmalloc(&h->cf_cnt, (size_t)p * off));
+                    CR(dmalloc(&ovf, 1));
+                    CH(hipMemsetAsync(ovf, 0, sizeof(int), h->stream));
+                    hipLaunchKernelGGL((k_pair_count_build<2>), dim3(cdiv(p, 2)), dim3(128), 0, h->stream, cf, h->cf_cnt, ovf);
+                    CH(hipGetLastError());
+                    int hv = 0;
+                    CH(hipMemcpyAsync(&hv, ovf, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                    CH(hipStreamSynchronize(h->stream));
+                    (void)hipFree(ovf);
+                    fits = hv == 0;
+                }
+                h->cf_pair_ok = fits;
+            }
         }
     }
     // the transposed copies were only needed to build the row-side lists
@@ -1206,7 +1256,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "profile") h->profile = (int)value;
     else if (s == "verbose") h->verbose = (int)value;
     else if (s == "force_allreduce") h->force_allreduce = (int)value;   // call the all-reduce callback even when world == 1
-    else if (s == "col_factored") h->col_factored = (int)value;   // 1 = factored column statistics when the cost model favours them (default), 2 = always, 0 = k_list_stats
+    else if (s == "col_factored") h->col_factored = (int)value;   // 1 = cost model picks list / look-up / pair-count form (default), 2 = look-up form, 3 = pair-count form, 0 = k_list_stats
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
@@ -1327,7 +1377,8 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     h->prof[8] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     h->prof[9] = (double)std::min<uint64_t>((uint64_t)iter + 1, (uint64_t)max_iter + 1);
     h->prof[10] = (double)sweeps_total;
-    h->prof[11] = (masked && use_col_factored(h) ? 1.0 : 0.0) + (use_merged(h, masked) ? 2.0 : 0.0);   // which statistics paths ran
+    h->prof[11] = (masked && use_col_factored(h) ? 1.0 : 0.0) + (use_merged(h, masked) ? 2.0 : 0.0) +
+                  (masked && col_stats_path(h) == 2 ? 4.0 : 0.0);   // which statistics paths ran
     clear_events(h);
     return INSIDER_OK;
 }

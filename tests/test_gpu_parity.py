@@ -38,9 +38,10 @@ def _need_gpu():
         pytest.fail("no HIP device visible: -m gpu tests need the MI355X box")
 
 
-# the masked statistics have two implementations each (per-entry lists / factored per level); a cost model picks one
-# per data set, so every case runs with both forced
-PATHS = {"fast": dict(row_merged=2, col_factored=2), "lists": dict(row_merged=0, col_factored=0)}
+# the masked statistics have several implementations each (per-entry lists / factored per level, the column side also
+# from dense per-gene pair counts); a cost model picks one per data set, so every case runs with each of them forced
+PATHS = {"fast": dict(row_merged=2, col_factored=2), "pair": dict(row_merged=2, col_factored=3),
+         "lists": dict(row_merged=0, col_factored=0)}
 
 
 # K + 1 <= 16 -> one MFMA block, <= 32 -> 2x2 blocks, ... : cover every block geometry and its edges
@@ -184,14 +185,16 @@ def test_ridge_column_kernel_instantiations(oracle, K, tuning):
     assert relerr(got, ref) < 1e-10, relerr(got, ref)
 
 
-@pytest.mark.parametrize("paths", ["fast", "lists"])
+@pytest.mark.parametrize("paths", ["fast", "pair", "lists"])
 @pytest.mark.parametrize("kw", [dict(level_counts=(6,), n=90, p=80, K=5),                       # a single covariate
                                 dict(level_counts=(300, 3), n=900, p=70, K=6, f=0.3),            # > 255 levels, > 64 per pass
                                 dict(level_counts=(3, 4, 2, 5, 3), n=360, p=90, K=7, f=0.2),     # five covariates
                                 dict(level_counts=(2, 2), n=40, p=300, K=18, f=0.5, with_na=True),  # long level groups
                                 # > 2048 held-out samples per gene: index staging overflows, several 512-entry tiles
-                                dict(level_counts=(5, 3), n=3000, p=24, K=4, f=0.8)],
-                         ids=["one-cov", "300-levels", "five-cov", "long-groups", "2400-held-out-per-gene"])
+                                dict(level_counts=(5, 3), n=3000, p=24, K=4, f=0.8),
+                                # ~400 held-out entries per (level, level) cell: the one-byte pair counts overflow
+                                dict(level_counts=(2, 2), n=2000, p=16, K=4, f=0.8)],
+                         ids=["one-cov", "300-levels", "five-cov", "long-groups", "2400-held-out-per-gene", "count-overflow"])
 def test_statistics_paths_on_odd_covariate_structures(oracle, kw, paths):
     w = workloads.small(seed=91, **kw)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
@@ -200,7 +203,9 @@ def test_statistics_paths_on_odd_covariate_structures(oracle, kw, paths):
     got = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=10, seed=4)
     pr = ds.profile()
     ds.close()
-    assert pr["row_merged"] == (paths == "fast") and pr["col_factored"] == (paths == "fast")
+    assert pr["row_merged"] == (paths != "lists") and pr["col_factored"] == (paths != "lists")
+    if paths == "pair":   # the pair-count form needs every count to fit one byte; else the look-up form runs
+        assert pr["col_pair"] == (kw["n"] != 2000)
     ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
                           max_iter=10, seed=4)
     for i, a in enumerate(ref["row_matrices"]):
@@ -285,7 +290,7 @@ def test_optimize_31_iterations(oracle, case, paths):
 
 @pytest.mark.parametrize("opts", [dict(cd_variant=1), dict(cd_variant=2), dict(order_mode=1), dict(max_sweeps=7),
                                   dict(cd_variant=1, max_sweeps=5, order_mode=1),
-                                  dict(cd_variant=2, max_sweeps=6, order_mode=1), dict(row_merged=0), dict(row_merged=2), dict(col_factored=0), dict(col_factored=2),
+                                  dict(cd_variant=2, max_sweeps=6, order_mode=1), dict(row_merged=0), dict(row_merged=2), dict(col_factored=0), dict(col_factored=2), dict(col_factored=3),
                                   dict(row_merged=0, col_factored=0)])
 def test_optimize_options(oracle, opts):
     # the alternative CD kernels (one group of lanes per gene; LDS-resident row16), cyclic sweep order, the sweep cap,

@@ -48,8 +48,8 @@ def _worker(rank, world, port, q, opts):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("opts", [dict(row_merged=2, col_factored=2), dict(row_merged=0, col_factored=0)],
-                         ids=["merged-factored", "per-entry"])
+@pytest.mark.parametrize("opts", [dict(row_merged=2, col_factored=2), dict(row_merged=2, col_factored=3), dict(row_merged=0, col_factored=0)],
+                         ids=["merged-factored", "merged-paircount", "per-entry"])
 def test_two_ranks_on_one_gpu_match_single_rank(opts):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
