@@ -177,7 +177,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath)).get(name, {})
-                traffic = tj.get("col_stats_bytes_per_launch" if prof.get("col_factored") else "list_stats_col_bytes_per_launch")
+                traffic = tj.get("pair_stats_bytes_per_launch" if prof.get("col_pair") else
+                                 "col_stats_bytes_per_launch" if prof.get("col_factored") else "list_stats_col_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -194,8 +195,10 @@ def main():
                        "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
                        "parallelism": (f"gene-shard x{world}" + (" (REHEARSAL: all ranks on one GPU, host-staged all-reduce)" if one_gpu else ""))
                                       if world > 1 else "single GPU"},
-            "roofline": {"kernel": ("k_col_factored + k_mm_rows(held-out level sums x row factors): the column-side masked Gram/XtY complement "
-                                    "statistics of every gene (the quantity BASELINE's metric 2 names), factored form")
+            "roofline": {"kernel": (("k_col_paircnt" if prof.get("col_pair") else "k_col_factored") +
+                                    " + k_mm_rows(held-out level sums x row factors): the column-side masked Gram/XtY complement "
+                                    "statistics of every gene (the quantity BASELINE's metric 2 names), " +
+                                    ("pair-count form" if prof.get("col_pair") else "look-up form"))
                                    if prof.get("col_factored") else
                                    "k_list_stats (masked Gram/XtY complement statistics over the held-out lists, column side)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -205,11 +208,13 @@ def main():
                          "fp64_frac": fl / (gram_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gram_ms > 0 else 0.0,
                          "row_update": "merged (per (level, gene) pair)" if prof.get("row_merged") else "per-sample statistics",
                          "note": ("achieved = SURVEY 8d's algorithmic bytes (8np X + np mask + 8nK + 8p(T+K) out) / time. "
-                                  "The factored kernel streams neither X nor the mask (x-statistics come from per-level sums built "
-                                  "once per data set; the Gram complement costs one rank-one term per (covariate, level) and "
-                                  "one table-row add per held-out entry), so measured traffic is ~0.11x the algorithmic bytes "
-                                  "and achieved can exceed the HBM peak; the same statistics from the per-entry list kernel "
-                                  "(k_list_stats, option col_factored=0) take 1.30 ms at c3 = 3.6 TB/s = 0.45 of peak, MFMA-f64-bound")
+                                  "The factored kernels stream neither X nor the mask (x-statistics come from per-level sums built "
+                                  "once per data set; the Gram complement costs one rank-one term per (covariate, level) plus "
+                                  "the product of the gene's dense level-pair counts with the factor table [pair-count form] or "
+                                  "one table-row add per held-out entry [look-up form]), so measured traffic is ~0.1x the "
+                                  "algorithmic bytes and achieved can exceed the HBM peak: the pair-count kernel is bound by its ~154 v_mfma_f64_16x16x4 per gene. "
+                                  "The same statistics from the per-entry list kernel (k_list_stats, option col_factored=0) "
+                                  "take 1.30 ms at c3 = 3.6 TB/s = 0.45 of peak")
                                  if prof.get("col_factored") else
                                  "MFMA-f64-bound: 3 v_mfma_f64_16x16x4 per 4 held-out entries (K <= 31); HBM traffic is ~0.23x the "
                                  "algorithmic bytes (the kernel reads held-out lists, not X)"},

@@ -95,8 +95,9 @@ int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, 
  * K <= 32: 0 = four genes per wavefront with the Gram matrix in registers, 2 = four genes per wavefront with the Gram
  * matrix in LDS, 1 = one lane group per gene; all three produce the same iterates), "row_merged" (1, default = masked
  * row update from per-(level, gene) weighted terms, 0 = from per-sample statistics; same results), "col_factored" (1,
- * default = column-side masked Gram statistics from per-(covariate, level) terms when a cost model favours them, 2 =
- * always, 0 = one rank-one update per held-out entry; same results), "force_allreduce" (1 = call the all-reduce callback even
+ * default = a cost model picks the form of the column-side masked Gram statistics, 0 = one rank-one update per held-out
+ * entry, 2 = per-(covariate, level) terms with one table look-up per entry, 3 = per-(covariate, level) terms from the
+ * gene's dense level-pair counts [falls back to 2 when a count exceeds one byte]; same results), "force_allreduce" (1 = call the all-reduce callback even
  * when world == 1: plumbing rehearsal). */
 int insider_hip_set_option(insider_hip_handle *h, const char *name, double value);
 
@@ -180,7 +181,7 @@ int insider_hip_masked_gram_rows(insider_hip_handle *h, const double *C, int K, 
  * out[0..11]: {column-side masked-Gram launches, total ms, row-side masked-Gram launches, total ms,
  *  column-solve (CD / ridge) launches, total ms, test-residual launches, total ms,
  *  optimize() wall ms, outer iterations run, elastic-net sweeps total, path flags (1 = factored column statistics, 2 =
- *  merged row update)}. */
+ *  merged row update, 4 = the factored column statistics ran in their pair-count form)}. */
 int insider_hip_get_profile(insider_hip_handle *h, double *out12);
 
 /* Diagnostics: per-gene sweep counts of the last column update (p ints), and the HIP-event time in ms of the
