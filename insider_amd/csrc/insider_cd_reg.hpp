@@ -210,7 +210,7 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
         const bool active = valid && !(fabs(q[u]) < thr);
         const double D = (valid ? Gll[u] : 1.0) + l2;
         S.beta[u] = active ? beta[u] : 0.0;                                               // :78
-        S.inv[u] = active ? 1.0 / D : 0.0;
+        S.inv[u] = active ? cd_rcp(D) : 0.0;
         S.h[u] = valid ? q[u] : 0.0;
         s_d[64 * u] = D;
         s_out[64 * u] = S.beta[u];
@@ -247,7 +247,7 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
                     const bool viol = gene_ok && 16 * u + i < K && S.inv[u] == 0.0 && fabs(S.h[u]) > la;
-                    if (viol) S.inv[u] = 1.0 / s_d[64 * u];                               // :123
+                    if (viol) S.inv[u] = cd_rcp(s_d[64 * u]);                               // :123
                     anyv = anyv || viol;
                 }
                 if ((__ballot(anyv) & rowmask) == 0) finish = true;                       // :120-121

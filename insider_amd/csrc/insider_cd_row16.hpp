@@ -144,7 +144,7 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
     for (int u = 0; u < SLOTS; ++u) {
         active[u] = valid[u] && !(fabs(q[u]) < thr);
         S.beta[u] = active[u] ? beta[u] : 0.0;                                            // :78
-        S.inv[u] = active[u] ? 1.0 / (gl[u] + l2) : 0.0;
+        S.inv[u] = active[u] ? cd_rcp(gl[u] + l2) : 0.0;
         S.h[u] = valid[u] ? q[u] : 0.0;
         S.col[u] = gbase + cid[u] * 8;
         GllT[16 * u + i] = gl[u];
@@ -228,7 +228,7 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {                                         // :118-119 (grad = -g, beta = 0)
                     const bool viol = gene_ok && 16 * u + i < K && S.inv[u] == 0.0 && fabs(g1[u]) > P.alpha * P.lambda;
-                    if (viol) { S.inv[u] = 1.0 / (gl[u] + l2); invT[cid[u]] = S.inv[u]; }  // :123
+                    if (viol) { S.inv[u] = cd_rcp(gl[u] + l2); invT[cid[u]] = S.inv[u]; }  // :123
                     anyv = anyv || viol;
                 }
                 if ((__ballot(anyv) & rowmask) == 0) finish = true;                       // :120-121

@@ -198,6 +198,12 @@ struct CdParams {
     const uint8_t *order;   // [max_sweeps][ORDER_ROW], see k_order_table
 };
 
+// 1 / (XtX_kk + lambda (1 - alpha)) of src/coordinate_descent.cpp:99-104.  A zero denominator means the coordinate's
+// regressor vanishes on the gene's training samples (a latent dimension that a pure lasso, alpha = 1, has switched off
+// in every gene makes the next row update return an exactly zero factor column): then u = 0 <= lambda alpha and the
+// reference returns 0 without dividing; 0 here gives the same update instead of 0 * inf.
+__device__ __forceinline__ double cd_rcp(double d) { return d > 0.0 ? 1.0 / d : 0.0; }
+
 template <int W>
 __device__ __forceinline__ double group_bcast(double v, int k, int lane)
 {
@@ -274,7 +280,7 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
     if (!active) beta = 0.0;                                                          // :78
     double h = valid ? q : 0.0;                                                       // :79 in covariance form
     for (int m = 0; m < K; ++m) h -= Goff[m * W + l] * group_bcast<W>(beta, m, lane);
-    const double rinv = 1.0 / (Gll + l2);
+    const double rinv = cd_rcp(Gll + l2);
     double inv = active ? rinv : 0.0;
     bool run = (__ballot(valid) & gmask) != 0;   // group holds a gene
     int sweep = 0, my_sweeps = 0;

@@ -241,6 +241,9 @@ CASES = {
     "k30": dict(K=30, n=150, p=90),          # row16 kernel, two slots, 2 padded positions
     "k40": dict(K=40, n=150, p=60),          # K > 32: one gene per wavefront (group kernel), 3x3 MFMA blocks
     "three_cov": dict(level_counts=(4, 3, 5), n=120, p=100),
+    # pure lasso (l2 = 0): latent dimensions die in every gene, the next row update returns exactly zero factor columns
+    # and XtX_kk + lambda (1 - alpha) = 0 for them (found by tools/fuzz_parity.py: 0 * inf in the sweep)
+    "lasso": dict(n=78, p=43, level_counts=(3, 9, 2, 8), K=13, f=0.07, lam=7.0, alpha=1.0, seed=962864),
 }
 
 
@@ -413,6 +416,45 @@ def test_c2_all_ones_mask_equals_unmasked(c2):
     ds.close()
     assert relerr(r1["column_factor"], r0["column_factor"]) < 1e-9
     np.testing.assert_allclose(r1["traj"][:, 3:8], r0["traj"][:, 3:8], rtol=1e-10)
+
+
+def test_c3_full_size_forms_agree_and_losses_recompute():
+    """BASELINE's headline configuration (10000 x 50000, K = 30) at full size: every form of the masked statistics
+    (per-entry lists / look-up / pair counts on the column side, per-sample / merged on the row side) gives the same
+    11-iteration trajectory, and the loss components recomputed in numpy from the returned factors match."""
+    w = workloads.make("c3")
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    runs = {}
+    for name, opts in PATHS.items():
+        for k, v in opts.items():
+            ds.set_option(k, v)
+        runs[name] = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=10, seed=3)
+        pr = ds.profile()
+        assert pr["col_factored"] == (name != "lists") and pr["col_pair"] == (name == "pair")
+    ds.close()
+    ref = runs["lists"]
+    assert np.all(np.diff(ref["traj"][:, 7]) < 0)                       # checkpoint losses decrease
+    for name in ("fast", "pair"):
+        np.testing.assert_allclose(runs[name]["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+        assert relerr(runs[name]["column_factor"], ref["column_factor"]) < 1e-7
+        for i in range(len(w.A0)):
+            assert relerr(runs[name]["row_matrices"][f"factor{i}"], ref["row_matrices"][f"factor{i}"]) < 1e-7
+    got = runs["pair"]
+    A = [got["row_matrices"][f"factor{i}"] for i in range(len(w.A0))]
+    C = got["column_factor"]
+    R = sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]))
+    sse = sse_te = 0.0
+    for b in range(0, w.p, 5000):                                        # gene blocks: bounded host memory
+        resid = w.X[:, b:b + 5000] - R @ C[:, b:b + 5000]
+        sse += float(np.sum(resid[w.M_train[:, b:b + 5000] != 0] ** 2))
+        sse_te += float(np.sum(resid[w.M_test[:, b:b + 5000] != 0] ** 2))
+    tr = got["traj"]
+    assert tr[-1, 3] == pytest.approx(sse / 2, rel=1e-10)
+    assert tr[-1, 4] == pytest.approx(w.lam * sum(np.sum(a ** 2) for a in A) / 2, rel=1e-12)
+    assert tr[-1, 5] == pytest.approx(w.lam * (1 - w.alpha) * np.sum(C ** 2) / 2, rel=1e-12)
+    assert tr[-1, 6] == pytest.approx(w.lam * w.alpha * np.sum(np.abs(C)), rel=1e-12)
+    assert got["test_rmse"] == pytest.approx(np.sqrt(sse_te / np.count_nonzero(w.M_test)), rel=1e-10)
+    assert got["train_rmse"] == pytest.approx(np.sqrt(sse / np.count_nonzero(w.M_train)), rel=1e-10)
 
 
 def test_allreduce_callback_plumbing_single_gpu(oracle):

@@ -1,0 +1,85 @@
+"""Randomised parity sweep (GPU): random small workloads (shapes, covariate structures, masks, NA entries, lambda / alpha,
+masked / unmasked, every form of the statistics kernels, every CD variant) through insider_hip_optimize against the
+CPU oracle.  Prints every case that disagrees; exit code 1 when any does.      python tools/fuzz_parity.py [cases] [seed]"""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+ge.build()
+from insider_amd import api, workloads
+from oracle import c_oracle   # test infrastructure: the checker
+c_oracle.build()
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+bad = 0
+t0 = time.time()
+for case in range(ncases):
+    c = int(rng.integers(1, 5))
+    levels = tuple(int(x) for x in rng.integers(1, 13, size=c))
+    if max(levels) == 1:
+        levels = levels[:-1] + (3,)
+    n = int(rng.integers(max(16, max(levels) * 2), 260))
+    p = int(rng.integers(5, 140))
+    K = int(rng.choice([1, 2, 3, 5, 8, 13, 15, 16, 17, 20, 23, 25, 30, 31, 32, 33, 40]))
+    tuning = int(rng.random() < 0.8)
+    kw = dict(n=n, p=p, level_counts=levels, K=K, f=float(rng.uniform(0.03, 0.6)), lam=float(rng.choice([0.3, 1.0, 2.0, 7.0])),
+              alpha=float(rng.choice([0.0, 0.1, 0.4, 0.8, 1.0])), tuning=tuning, seed=int(rng.integers(1, 10 ** 6)),
+              with_na=bool(rng.random() < 0.3))
+    if c >= 2 and rng.random() < 0.25:
+        kw["interaction_idx"] = (1, 2)
+    opts = dict(row_merged=int(rng.choice([0, 1, 2])), col_factored=int(rng.choice([0, 1, 2, 3])),
+                cd_variant=int(rng.choice([0, 0, 0, 1, 2])))
+    iters = int(rng.choice([0, 1, 3]))
+    seed = int(rng.integers(1, 1000))
+    m = int(rng.choice([0, 0, 0, 1, 3]))   # continuous covariates (optimize_continuous_v2)
+    try:
+        w = workloads.small(**kw)
+    except AssertionError:
+        continue   # a level that never occurs: not a valid data set
+    rs = np.random.default_rng(seed)
+    scale = float(rng.choice([0.001, 0.3]))
+    A = [np.asfortranarray(rs.standard_normal(a.shape) * scale) for a in w.A0]
+    C = np.asfortranarray(rs.standard_normal(w.C0.shape) * scale)
+    Z = None
+    if m:
+        Z = np.asfortranarray(rs.standard_normal((w.n, m)))
+        A = A + [np.asfortranarray(rs.standard_normal((m, w.K)) * scale)]
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
+    for k, v in opts.items():
+        ds.set_option(k, v)
+    ds.set_option("max_sweeps", 300)
+    try:
+        got = ds.optimize([a.copy(order="F") for a in A], C.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=tuning,
+                          max_iter=iters, seed=seed, inc_continuous=1 if m else 0)
+        err = None
+    except Exception as e:   # both sides must then fail
+        got, err = None, e
+    ds.close()
+    try:
+        ref = c_oracle.optimize(w.X, w.levels, w.n_levels, A, C, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=tuning,
+                                max_iter=iters, seed=seed, max_sweeps=300, **(dict(ctns=Z) if m else {}))
+        rerr = None
+    except Exception as e:
+        ref, rerr = None, e
+    msg = None
+    if (got is None) != (ref is None):
+        msg = f"one side failed: hip {err!r} oracle {rerr!r}"
+    elif got is not None:
+        e_row = max(relerr(got["row_matrices"][f"factor{i}"], a) for i, a in enumerate(ref["row_matrices"]))
+        e_col = relerr(got["column_factor"], ref["column_factor"])
+        tg, tr = got["traj"][:, 1:8], ref["traj"][:, 1:8]
+        e_traj = float(np.nanmax(np.abs(tg - tr) / np.maximum(np.abs(tr), 1e-300))) if tg.shape == tr.shape and tg.size else (0.0 if tg.shape == tr.shape else np.inf)
+        tol = 1e-6 if m else 1e-7   # the continuous update solves an m x m system whose conditioning the data sets
+        if not (e_row < tol and e_col < tol and e_traj < 1e-8 and got["iters"] == ref["iters"]):
+            msg = f"row {e_row:.2e} col {e_col:.2e} traj {e_traj:.2e} iters {got['iters']} vs {ref['iters']}"
+    if msg:
+        bad += 1
+        print(f"MISMATCH case {case}: {kw} opts {opts} iters {iters} seed {seed} scale {scale} m {m}: {msg}", flush=True)
+    if case % 25 == 24:
+        print(f"... {case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(f"{ncases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
