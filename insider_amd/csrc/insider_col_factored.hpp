@@ -331,6 +331,76 @@ __global__ void __launch_bounds__(WPB * 64) k_pair_count_build(ColFacArgs a, uin
     }
 }
 
+// u_j[l] = sum_{r in l ∩ H(j)} sum_{m != i} V_j[level_m(r)] of the merged row update (insider_row_merged.hpp, k_gene_u)
+// from the same dense pair counts: for the covariate at position t,
+//   u[l] = sum_q n^t_j(l, q) V_j[q]  (its own table: the covariates after it)
+//        + sum_{t' < t} sum_{l'} n^{t'}_j(l', column of (t, l)) V_j[level l' of t']  (the tables of the covariates before it,
+//                                                                                     read transposed).
+// One wave per gene, ~20 instructions per block of 16 levels instead of one look-up per held-out entry and other covariate.
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, int LP, const double *__restrict__ V, int SLP,
+                                                         int SL, double *__restrict__ U)
+{
+    extern __shared__ double s_uc[];   // per wave: V row [SL] | out [LP] | 64 partials
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * WPB + w;
+    if (j >= a.p) return;
+    double *v = s_uc + (size_t)w * (SL + LP + WAVE), *out = v + SL, *red = out + LP;
+    for (int q = lane; q < SL; q += WAVE) v[q] = V[(size_t)j * SLP + q];
+    for (int l = lane; l < LP; l += WAVE) out[l] = 0.0;
+    wave_sync();
+    const int g4 = lane >> 4, c16 = lane & 15;
+    const int bpl = a.nsteps <= 4 ? 4 : 8;
+    const uint8_t *cj = a.cnt + (size_t)j * a.cnt_stride;
+    const int Lt = a.L[t];
+    if (a.nlater[t] > 0) {   // its own table: rows = its levels, columns = table rows of the later covariates
+        double vq[CP_MAXSTEPS];
+#pragma unroll
+        for (int s = 0; s < CP_MAXSTEPS; ++s) {
+            const int r = 4 * s + g4;
+            const int q = r < a.tab_skip_lo ? r : r + a.tab_skip_n;
+            vq[s] = (s < a.nsteps && r < a.tab_rows) ? v[q] : 0.0;
+        }
+        const uint8_t *ct = cj + a.cnt_off[t];
+        for (int l0 = 0; l0 < Lt; l0 += 16) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)(l0 >> 4) * 64 + lane) * bpl);
+            uint32_t cw[2] = {src[0], bpl == 8 ? src[1] : 0u};
+            double part = 0.0;
+#pragma unroll
+            for (int s = 0; s < CP_MAXSTEPS; ++s) part = fma((double)((cw[s >> 2] >> (8 * (s & 3))) & 0xffu), vq[s], part);
+            red[lane] = part;
+            wave_sync();
+            if (g4 == 0 && l0 + c16 < Lt) out[l0 + c16] = ((red[c16] + red[16 + c16]) + red[32 + c16]) + red[48 + c16];
+            wave_sync();
+        }
+    }
+    for (int tp = 0; tp < t; ++tp) {   // the tables of the covariates before it: columns of (t, l), transposed
+        const int Lp = a.L[tp];
+        const uint8_t *ct = cj + a.cnt_off[tp];
+        double acc[CP_MAXSTEPS];
+#pragma unroll
+        for (int s = 0; s < CP_MAXSTEPS; ++s) acc[s] = 0.0;
+        for (int l0 = 0; l0 < Lp; l0 += 16) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)(l0 >> 4) * 64 + lane) * bpl);
+            uint32_t cw[2] = {src[0], bpl == 8 ? src[1] : 0u};
+            const double vv = l0 + c16 < Lp ? v[a.off[tp] + l0 + c16] : 0.0;
+#pragma unroll
+            for (int s = 0; s < CP_MAXSTEPS; ++s) acc[s] = fma((double)((cw[s >> 2] >> (8 * (s & 3))) & 0xffu), vv, acc[s]);
+        }
+        const int qs = a.off[t];                                              // stacked index of level 0 of (t)
+        const int c_lo = qs < a.tab_skip_lo ? qs : qs - a.tab_skip_n;          // its table column
+#pragma unroll
+        for (int s = 0; s < CP_MAXSTEPS; ++s) {
+            const double tot = row16_sum(acc[s]);
+            const int l = 4 * s + g4 - c_lo;
+            if (s < a.nsteps && c16 == 0 && l >= 0 && l < Lt) out[l] += tot;
+        }
+        wave_sync();
+    }
+    wave_sync();
+    for (int l = lane; l < LP; l += WAVE) U[(size_t)j * LP + l] = l < Lt ? out[l] : 0.0;
+}
+
 // Sheld = S - Strain (once per data set)
 __global__ void __launch_bounds__(256) k_sub(const double *__restrict__ a, const double *__restrict__ b, size_t n,
                                              double *__restrict__ out)

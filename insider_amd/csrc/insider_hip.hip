@@ -112,6 +112,8 @@ struct insider_hip_handle {
     int col_factored = 1;             // option: factored column statistics (insider_col_factored.hpp): 0 list kernel, 1 cost model, 2 look-up form, 3 pair-count form
     uint8_t *cf_cnt = nullptr;        // dense pair counts of every gene (pair-count form), static per data set
     bool cf_pair_ok = false;
+    int cf_pos[CF_MAXC] = {0};        // position of covariate i in cf's order (decreasing level count)
+    int row_counts = 1;               // option: k_gene_u from the dense pair counts when they exist
     ColFacArgs cf;                    // its static part (filled at create)
     size_t cf_lds = 0;
     double *U = nullptr, *Ylvl = nullptr, *wpart = nullptr, *Vlev = nullptr;   // merged row update workspace
@@ -642,10 +644,18 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
     if (!cont && use_merged(h, masked)) {
         // merged update: one weighted rank-one term per (level, gene) pair, one look-up per held-out entry
         const int L = ct.L, LP = (int)round_up(L, 2), KP = h->KP;
-        hipLaunchKernelGGL((k_gene_u<4>), dim3(cdiv(h->p, 4)), dim3(256), (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double),
-                           h->stream, (const uint32_t *)ct.grp, (const uint16_t *)ct.slev,
-                           (size_t)h->col_entries + LIST_BLOCK, h->c - 1, L, LP, (const double *)h->Vlev, h->SLP, (int)h->p,
-                           h->SLcat, h->U);
+        if (h->cf_pair_ok && h->row_counts && h->c <= CF_MAXC) {   // u from the dense pair counts (insider_col_factored.hpp)
+            ColFacArgs ca = h->cf;
+            ca.cnt = h->cf_cnt;
+            hipLaunchKernelGGL((k_gene_u_cnt<4>), dim3(cdiv(h->p, 4)), dim3(256),
+                               (size_t)4 * (h->SLcat + LP + WAVE) * sizeof(double), h->stream, ca, h->cf_pos[i], LP,
+                               (const double *)h->Vlev, h->SLP, h->SLcat, h->U);
+        } else {
+            hipLaunchKernelGGL((k_gene_u<4>), dim3(cdiv(h->p, 4)), dim3(256), (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double),
+                               h->stream, (const uint32_t *)ct.grp, (const uint16_t *)ct.slev,
+                               (size_t)h->col_entries + LIST_BLOCK, h->c - 1, L, LP, (const double *)h->Vlev, h->SLP, (int)h->p,
+                               h->SLcat, h->U);
+        }
         KCHECK();
         // Y = U'C, the same reduction over genes as (S C')
         if (int rcy = launch_mm_reduce_kp(h, h->U, LP, h->C, (int)h->p, L, h->sc_part, h->Ylvl)) return rcy;
@@ -1184,6 +1194,7 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
             cf.plane = (size_t)h->col_entries + LIST_BLOCK;
             for (int t = 0; t < c; ++t) {
                 const int o = ord[t];
+                h->cf_pos[o] = t;
                 cf.grp[t] = h->cov[o].grp;
                 cf.slev[t] = h->cov[o].slev;
                 cf.L[t] = n_levels[o];
@@ -1257,6 +1268,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "verbose") h->verbose = (int)value;
     else if (s == "force_allreduce") h->force_allreduce = (int)value;   // call the all-reduce callback even when world == 1
     else if (s == "col_factored") h->col_factored = (int)value;   // 1 = cost model picks list / look-up / pair-count form (default), 2 = look-up form, 3 = pair-count form, 0 = k_list_stats
+    else if (s == "row_counts") h->row_counts = (int)value;   // 1 = the merged row update takes u from the dense pair counts when they exist (default), 0 = from the entry lists
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);

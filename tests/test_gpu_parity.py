@@ -40,7 +40,7 @@ def _need_gpu():
 
 # the masked statistics have several implementations each (per-entry lists / factored per level, the column side also
 # from dense per-gene pair counts); a cost model picks one per data set, so every case runs with each of them forced
-PATHS = {"fast": dict(row_merged=2, col_factored=2), "pair": dict(row_merged=2, col_factored=3),
+PATHS = {"fast": dict(row_merged=2, col_factored=2, row_counts=0), "pair": dict(row_merged=2, col_factored=3, row_counts=1),
          "lists": dict(row_merged=0, col_factored=0)}
 
 

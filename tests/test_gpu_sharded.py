@@ -48,7 +48,7 @@ def _worker(rank, world, port, q, opts):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("opts", [dict(row_merged=2, col_factored=2), dict(row_merged=2, col_factored=3), dict(row_merged=0, col_factored=0)],
+@pytest.mark.parametrize("opts", [dict(row_merged=2, col_factored=2, row_counts=0), dict(row_merged=2, col_factored=3), dict(row_merged=0, col_factored=0)],
                          ids=["merged-factored", "merged-paircount", "per-entry"])
 def test_two_ranks_on_one_gpu_match_single_rank(opts):
     s = socket.socket()

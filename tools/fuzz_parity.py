@@ -32,7 +32,7 @@ for case in range(ncases):
     if c >= 2 and rng.random() < 0.25:
         kw["interaction_idx"] = (1, 2)
     opts = dict(row_merged=int(rng.choice([0, 1, 2])), col_factored=int(rng.choice([0, 1, 2, 3])),
-                cd_variant=int(rng.choice([0, 0, 0, 1, 2])))
+                cd_variant=int(rng.choice([0, 0, 0, 1, 2])), row_counts=int(rng.integers(0, 2)))
     iters = int(rng.choice([0, 1, 3]))
     seed = int(rng.integers(1, 1000))
     m = int(rng.choice([0, 0, 0, 1, 3]))   # continuous covariates (optimize_continuous_v2)
