@@ -97,7 +97,8 @@ int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, 
  * row update from per-(level, gene) weighted terms, 0 = from per-sample statistics; same results), "col_factored" (1,
  * default = a cost model picks the form of the column-side masked Gram statistics, 0 = one rank-one update per held-out
  * entry, 2 = per-(covariate, level) terms with one table look-up per entry, 3 = per-(covariate, level) terms from the
- * gene's dense level-pair counts [falls back to 2 when a count exceeds one byte]; same results), "force_allreduce" (1 = call the all-reduce callback even
+ * gene's dense level-pair counts [falls back to 2 when a count exceeds one byte]; same results), "row_counts" (1, default = the merged row update takes its per-gene level sums from the dense
+ * level-pair counts when they exist, 0 = from the entry lists; same results), "force_allreduce" (1 = call the all-reduce callback even
  * when world == 1: plumbing rehearsal). */
 int insider_hip_set_option(insider_hip_handle *h, const char *name, double value);
 
