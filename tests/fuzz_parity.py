@@ -1,6 +1,6 @@
 """Randomised parity sweep (GPU): random small workloads (shapes, covariate structures, masks, NA entries, lambda / alpha,
 masked / unmasked, every form of the statistics kernels, every CD variant) through insider_hip_optimize against the
-CPU oracle.  Prints every case that disagrees; exit code 1 when any does.      python tools/fuzz_parity.py [cases] [seed]"""
+CPU oracle.  Prints every case that disagrees; exit code 1 when any does.      python tests/fuzz_parity.py [cases] [seed]"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,7 @@ for case in range(ncases):
         levels = levels[:-1] + (3,)
     n = int(rng.integers(max(16, max(levels) * 2), 260))
     p = int(rng.integers(5, 140))
-    K = int(rng.choice([1, 2, 3, 5, 8, 13, 15, 16, 17, 20, 23, 25, 30, 31, 32, 33, 40]))
+    K = int(rng.choice([1, 2, 3, 5, 8, 13, 15, 16, 17, 20, 23, 25, 30, 31, 32, 33, 40, 47, 48, 63]))
     tuning = int(rng.random() < 0.8)
     kw = dict(n=n, p=p, level_counts=levels, K=K, f=float(rng.uniform(0.03, 0.6)), lam=float(rng.choice([0.3, 1.0, 2.0, 7.0])),
               alpha=float(rng.choice([0.0, 0.1, 0.4, 0.8, 1.0])), tuning=tuning, seed=int(rng.integers(1, 10 ** 6)),

@@ -242,7 +242,7 @@ CASES = {
     "k40": dict(K=40, n=150, p=60),          # K > 32: one gene per wavefront (group kernel), 3x3 MFMA blocks
     "three_cov": dict(level_counts=(4, 3, 5), n=120, p=100),
     # pure lasso (l2 = 0): latent dimensions die in every gene, the next row update returns exactly zero factor columns
-    # and XtX_kk + lambda (1 - alpha) = 0 for them (found by tools/fuzz_parity.py: 0 * inf in the sweep)
+    # and XtX_kk + lambda (1 - alpha) = 0 for them (found by tests/fuzz_parity.py: 0 * inf in the sweep)
     "lasso": dict(n=78, p=43, level_counts=(3, 9, 2, 8), K=13, f=0.07, lam=7.0, alpha=1.0, seed=962864),
 }
 
