@@ -195,7 +195,15 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
                                       int lane, double *stash)
 {
     const int row = lane >> 4, i = lane & 15;
-    const double la = P.la, l2 = P.l2;
+    // the scalars the sweep loop needs, copied out of the kernel-argument tuple: the sweep's assembly clobbers s63-s99,
+    // and the compiler otherwise keeps the s_load_dwordx8 result there and restores it (8 v_readlane) twice per sweep
+    double la = P.la, tol = P.tol;
+    const double l2 = P.l2;
+    int max_sweeps = P.max_sweeps;
+    const uint8_t *order = P.order;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(la), "+s"(tol), "+s"(max_sweeps), "+s"(order));
+#endif
     const uint64_t rowmask = 0xffffull << (16 * row);
     double *s_d = stash + lane, *s_b = s_d + 128, *s_w = s_d + 256, *s_out = s_d + 384;   // [slot * 64]
     // ---- strong rule and start values (:74-80) ---------------------------------------------------------------
@@ -226,7 +234,7 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
     int sweep = 0, my_sweeps = 0;
     while (__any(run)) {
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
-        reg_sweep(S, G, la, reinterpret_cast<const uint32_t *>(P.order + (size_t)sweep * ORDER_ROW + REG_ORDER_OFF));
+        reg_sweep(S, G, la, reinterpret_cast<const uint32_t *>(order + (size_t)sweep * ORDER_ROW + REG_ORDER_OFF));
         ++sweep;
         // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
         double acc = 0.0, acc1 = 0.0;
@@ -241,8 +249,8 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
         }
         const double dloss = row16_sum(fma(la, acc1, 0.5 * acc));
         if (run) {
-            bool finish = sweep >= P.max_sweeps;
-            if (!finish && !(fabs(dloss) > P.tol)) {                                      // :114
+            bool finish = sweep >= max_sweeps;
+            if (!finish && !(fabs(dloss) > tol)) {                                        // :114
                 bool anyv = false;
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
