@@ -33,23 +33,23 @@ struct RegState {
 // Block for coordinate KK (slot s = KK / 16, owner lane it = KK % 16), src/coordinate_descent.cpp:91-110 in covariance
 // form: x = soft(h_s, la); dn = beta_s - x inv_s (one fma: minus the increment); beta_s[it] -= dn;
 // h_u += bcast_it(dn) * G_u[KK].  soft(h, la) = h - clamp(h, -la, la); x = 0 gives dn = beta_s and beta_s[it] = 0 exactly.  Screened-out coordinates and parked genes carry inv = beta = 0, i.e. a zero increment.
-// The sweep's 34 block offsets (positions 0..33; position K and beyond hold the exit block) are loaded into
-// s[64:97] at the start of the sweep and turned into the low words of the block addresses; the table of blocks
-// (REG_BLOCK bytes apart, placed with .org, which also asserts that no block outgrows its slot) starts on a 4 KiB
-// boundary and is shorter than 4 KiB, so it cannot straddle a 4 GiB boundary and the high word of every block address
-// is the same (vcc_hi, set once).  The block of position t fetches the address of the block of position t+1 with
-// s_movrels (M0 = t+1) into vcc_lo while the vector chain runs, and jumps.  Critical chain per step: min, max, add,
-// fma (dn), DPP fmac.  Hazards respected by construction: >= 2 instructions between the write of dn and its DPP read;
-// >= 1 between the write of M0 and s_movrels; exec is written by SALU only; nothing in a block writes vcc_hi.
+// The sweep's order arrives as a successor list of code-block offsets (k_order_table: dword 0 = first block, dword 1 + k
+// = the block visited after coordinate k, the exit block after the last), loaded into s[64:97] at the start of the sweep
+// and turned into the low words of the block addresses; the table of blocks (REG_BLOCK bytes apart, placed with .org,
+// which also asserts that no block outgrows its slot) starts on a 4 KiB boundary and is shorter than 4 KiB, so it cannot
+// straddle a 4 GiB boundary and the high word of every block address is the same (vcc_hi, set once).  Block k copies its
+// successor's address from its own table register s[65 + k] into vcc_lo while the vector chain runs, and jumps: no
+// position counter, M0 untouched.  Critical chain per step: min, max, add, fma (dn), DPP fmac.  Hazards respected by
+// construction: >= 2 instructions between the write of dn and its DPP read; exec is written by SALU only; nothing in a
+// block writes vcc_hi.
 #define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
     ".org Lc%= + 96*" #KK "\n"                                   \
-    "s_movrels_b32 vcc_lo, s64\n"                                \
+    "s_mov_b32 vcc_lo, s[65+" #KK "]\n"                          \
     "v_min_f64 %[c], %[" HS "], %[la]\n"                         \
     "v_max_f64 %[c], %[c], -%[la]\n"                             \
     "v_add_f64 %[c], %[" HS "], -%[c]\n"                         \
     "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
-    "s_add_u32 m0, m0, 1\n"                                      \
     "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
     "s_mov_b64 exec, %[ex]\n"
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
@@ -62,8 +62,6 @@ struct RegState {
     "s_add_u32 s" #A ", s" #A ", s98\n s_add_u32 s" #B ", s" #B ", s98\n s_add_u32 s" #C ", s" #C ", s98\n s_add_u32 s" #D ", s" #D ", s98\n"
 #define REG_PROLOGUE                               \
     "s_mov_b64 %[ex], exec\n"                      \
-    "s_mov_b32 %[sk], m0\n"                        \
-    "s_mov_b32 s63, %[sk]\n"                       \
     "s_load_dwordx16 s[64:79], %[tb], 0x0\n"       \
     "s_load_dwordx16 s[80:95], %[tb], 0x40\n"      \
     "s_load_dwordx2 s[96:97], %[tb], 0x80\n"       \
@@ -71,7 +69,6 @@ struct RegState {
     "Lr%=:\n"                                      \
     "s_add_u32 s98, s98, Lc%=-Lr%=\n"              \
     "s_addc_u32 s99, s99, 0\n"                     \
-    "s_mov_b32 m0, 1\n"                            \
     "s_mov_b32 vcc_hi, s99\n"                      \
     "s_waitcnt lgkmcnt(0)\n"                       \
     REG_ADDR4(64, 65, 66, 67) REG_ADDR4(68, 69, 70, 71) REG_ADDR4(72, 73, 74, 75) REG_ADDR4(76, 77, 78, 79)            \
@@ -84,9 +81,9 @@ struct RegState {
     "s_setpc_b64 vcc\n"                            \
     ".p2align 12\n"                                \
     "Lc%=:\n"
-#define REG_EPILOGUE(NBLK) ".org Lc%= + 96*" #NBLK "\n s_mov_b32 m0, s63\n s_waitcnt lgkmcnt(0)\n"   /* exit: M0 as on entry */
+#define REG_EPILOGUE(NBLK) ".org Lc%= + 96*" #NBLK "\n s_waitcnt lgkmcnt(0)\n"   /* exit block */
 #define REG_CLOBBERS                                                                                                     \
-    "vcc", "scc", "memory", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",   \
+    "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",   \
         "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",  \
         "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 #define REG_GA(KK) [ga##KK] "v"(G[0][KK]),

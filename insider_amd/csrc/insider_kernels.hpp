@@ -351,32 +351,39 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
 
 // Order table, one row of ORDER_ROW bytes per sweep s < nsweeps: bytes [0, 64): the K coordinates in ascending key
 // order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
-// the row16 kernel, K <= 32); bytes [128, 320): 48 uint32 = coordinate * 96 for positions < K and exit_block * 96
-// beyond (code-block offsets of the register-resident kernel, insider_cd_reg.hpp).  One thread per (sweep,
-// coordinate): rank by counting.
+// the row16 kernel, K <= 32); bytes [128, 320): 48 uint32, the code-block offsets of the register-resident kernel
+// (insider_cd_reg.hpp) as a successor list: dword 0 = 96 * (first coordinate of the sweep), dword 1 + k = 96 * (the
+// coordinate visited after k), exit_block for the last one and for k >= K.  One thread per (sweep, coordinate): rank
+// by counting.
 __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
                                                      int pitch_bytes, int exit_block, uint8_t *__restrict__ order)
 {
+    __shared__ uint8_t by_rank[4][64];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = t >> 6, l = t & 63;
-    if (s >= nsweeps) return;
-    uint8_t *row = order + (size_t)s * ORDER_ROW;
-    if (l >= K) {
-        row[l] = 0;
-        if (l < 32) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
-        if (l < 48) reinterpret_cast<uint32_t *>(row + 128)[l] = (uint32_t)exit_block * 96u;
-        return;
-    }
+    const int s = t >> 6, l = t & 63, w = threadIdx.x >> 6;
+    const bool live = s < nsweeps;
+    uint8_t *row = order + (size_t)(live ? s : 0) * ORDER_ROW;
     int rank = l;
-    if (order_mode == 0) {
+    if (live && l < K && order_mode == 0) {
         const uint32_t base = insider_perm_base(seed, iter, (uint32_t)s);
         const uint32_t key = insider_perm_key(base, (uint32_t)l);
         rank = 0;
         for (int m = 0; m < K; ++m) rank += insider_perm_key(base, (uint32_t)m) < key;
     }
+    if (l < K) by_rank[w][rank] = (uint8_t)l;
+    __syncthreads();
+    if (!live) return;
+    uint32_t *blk = reinterpret_cast<uint32_t *>(row + 128);
+    if (l >= K) {
+        row[l] = 0;
+        if (l < 32) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
+        if (l < 47) blk[1 + l] = (uint32_t)exit_block * 96u;
+        return;
+    }
     row[rank] = (uint8_t)l;
     if (rank < 32) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
-    if (rank < 48) reinterpret_cast<uint32_t *>(row + 128)[rank] = (uint32_t)l * 96u;
+    if (l < 47) blk[1 + l] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * 96u : (uint32_t)exit_block * 96u;
+    if (rank == 0) blk[0] = (uint32_t)l * 96u;
 }
 
 // ---------------------------------------------------------------------------------------------
