@@ -35,16 +35,16 @@ struct RegState {
 // h_u += bcast_it(dn) * G_u[KK].  soft(h, la) = h - clamp(h, -la, la); x = 0 gives dn = beta_s and beta_s[it] = 0 exactly.  Screened-out coordinates and parked genes carry inv = beta = 0, i.e. a zero increment.
 // The sweep's order arrives as a successor list of code-block offsets (k_order_table: dword 0 = first block, dword 1 + k
 // = the block visited after coordinate k, the exit block after the last), loaded into s[64:97] at the start of the sweep
-// and turned into the low words of the block addresses; the table of blocks (REG_BLOCK bytes apart, placed with .org,
+// (offsets: each block adds the table's base address, s98, itself); the table of blocks (REG_BLOCK bytes apart, placed with .org,
 // which also asserts that no block outgrows its slot) starts on a 4 KiB boundary and is shorter than 4 KiB, so it cannot
-// straddle a 4 GiB boundary and the high word of every block address is the same (vcc_hi, set once).  Block k copies its
-// successor's address from its own table register s[65 + k] into vcc_lo while the vector chain runs, and jumps: no
+// straddle a 4 GiB boundary and the high word of every block address is the same (vcc_hi, set once).  Block k forms its
+// successor's address from its own table register s[65 + k] in vcc_lo while the vector chain runs, and jumps: no
 // position counter, M0 untouched.  Critical chain per step: min, max, add, fma (dn), DPP fmac.  Hazards respected by
 // construction: >= 2 instructions between the write of dn and its DPP read; exec is written by SALU only; nothing in a
 // block writes vcc_hi.
 #define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
     ".org Lc%= + 96*" #KK "\n"                                   \
-    "s_mov_b32 vcc_lo, s[65+" #KK "]\n"                          \
+    "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
     "v_min_f64 %[c], %[" HS "], %[la]\n"                         \
     "v_max_f64 %[c], %[c], -%[la]\n"                             \
     "v_add_f64 %[c], %[" HS "], -%[c]\n"                         \
@@ -58,8 +58,6 @@ struct RegState {
 #define REG_BLOCK2_HI(KK, IT) \
     REG_BLOCK_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) "s_setpc_b64 vcc\n"
 #define REG_BLOCK1(KK) REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) "s_setpc_b64 vcc\n"
-#define REG_ADDR4(A, B, C, D) \
-    "s_add_u32 s" #A ", s" #A ", s98\n s_add_u32 s" #B ", s" #B ", s98\n s_add_u32 s" #C ", s" #C ", s98\n s_add_u32 s" #D ", s" #D ", s98\n"
 #define REG_PROLOGUE                               \
     "s_mov_b64 %[ex], exec\n"                      \
     "s_load_dwordx16 s[64:79], %[tb], 0x0\n"       \
@@ -71,13 +69,10 @@ struct RegState {
     "s_addc_u32 s99, s99, 0\n"                     \
     "s_mov_b32 vcc_hi, s99\n"                      \
     "s_waitcnt lgkmcnt(0)\n"                       \
-    REG_ADDR4(64, 65, 66, 67) REG_ADDR4(68, 69, 70, 71) REG_ADDR4(72, 73, 74, 75) REG_ADDR4(76, 77, 78, 79)            \
-    REG_ADDR4(80, 81, 82, 83) REG_ADDR4(84, 85, 86, 87) REG_ADDR4(88, 89, 90, 91) REG_ADDR4(92, 93, 94, 95)            \
-    "s_add_u32 s96, s96, s98\n s_add_u32 s97, s97, s98\n" \
     "s_load_dword %[sk], %[tb], 0x140\n"           /* touch the next sweep's row (ORDER_ROW = 0x140 further): */ \
     "s_load_dword %[p1], %[tb], 0x180\n"           /* its three lines are in the scalar cache when that sweep */ \
     "s_load_dword %[p2], %[tb], 0x1c0\n"           /* starts; waited for in the exit block                    */ \
-    "s_mov_b32 vcc_lo, s64\n"                      \
+    "s_add_u32 vcc_lo, s64, s98\n"                 \
     "s_setpc_b64 vcc\n"                            \
     ".p2align 12\n"                                \
     "Lc%=:\n"
