@@ -222,11 +222,16 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
         s_w[64 * u] = fma(S.beta[u], s_d[64 * u], -S.h[u]);
     }
 
-    bool run = gene_ok;
+    // Loop control lives in scalar registers: `runm` = lane mask of the genes still running (a wave-uniform integer,
+    // changed only in the rarely taken finishing path), the sweep number and the order-table pointer.  Per sweep the
+    // control costs one vector compare (the convergence test) and scalar mask arithmetic.
+    uint64_t runm = __ballot(gene_ok);
     int sweep = 0, my_sweeps = 0;
-    while (__any(run)) {
+    const uint32_t *tb = reinterpret_cast<const uint32_t *>(order + REG_ORDER_OFF);
+    while (runm != 0) {
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
-        reg_sweep(S, G, la, reinterpret_cast<const uint32_t *>(order + (size_t)sweep * ORDER_ROW + REG_ORDER_OFF));
+        reg_sweep(S, G, la, tb);
+        tb += ORDER_ROW / 4;
         ++sweep;
         // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
         double acc = 0.0, acc1 = 0.0;
@@ -240,18 +245,21 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             s_w[64 * u] = w1;
         }
         const double dloss = row16_sum(fma(la, acc1, 0.5 * acc));
-        if (run) {
-            bool finish = sweep >= max_sweeps;
-            if (!finish && !(fabs(dloss) > tol)) {                                        // :114
-                bool anyv = false;
+        const uint64_t convm = __ballot(!(fabs(dloss) > tol));                             // :114
+        const uint64_t cand = sweep >= max_sweeps ? runm : (convm & runm);                  // genes that may stop now
+        if (cand != 0) {                                                                    // wave-uniform, rarely taken
+            const bool mine = (cand >> lane) & 1ull;
+            bool finish = mine && sweep >= max_sweeps;
+            bool anyv = false;
+            if (mine && !finish) {
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
                     const bool viol = gene_ok && 16 * u + i < K && S.inv[u] == 0.0 && fabs(S.h[u]) > la;
                     if (viol) S.inv[u] = cd_rcp(s_d[64 * u]);                               // :123
                     anyv = anyv || viol;
                 }
-                if ((__ballot(anyv) & rowmask) == 0) finish = true;                       // :120-121
             }
+            if (mine && !finish && (__ballot(anyv) & rowmask) == 0) finish = true;        // :120-121
             if (finish) {   // park the row: zero increments from now on
                 my_sweeps = sweep;
 #pragma unroll
@@ -260,8 +268,8 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
                     S.beta[u] = 0.0;
                     S.inv[u] = 0.0;
                 }
-                run = false;
             }
+            runm &= ~__ballot(finish);
         }
     }
 #pragma unroll
