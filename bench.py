@@ -225,13 +225,11 @@ def main():
                           "coordinate_updates_per_s": prof["sweeps"] * K / max(prof["cd_ms"] * 1e-3, 1e-9),
                           # the largest share of wall time: a sequential recurrence per gene, neither HBM- nor MFMA-bound.
                           # One coordinate step of a wave's 4 genes = 7 fp64 VALU instructions (4 cycles each on one of
-                          # 1024 SIMDs: the issue bound quoted here) + one computed jump; measured on this part
-                          # (tools/ubench5.hip) a CU retires one computed jump per ~4.7 ns, i.e. 18.8 ns per step per SIMD,
-                          # which is what binds at K = 30
-                          "bound": "fp64 VALU issue, 7 instructions per coordinate step of 4 genes (in practice the CU's taken-branch rate)",
+                          # 1024 SIMDs: the issue bound quoted here at the nominal 2.4 GHz) + 4 scalar instructions + one
+                          # computed jump (~4.5 ns of SIMD time, tools/ubench5/7.hip); see DESIGN.md 4.2
+                          "bound": "fp64 VALU issue, 7 instructions per coordinate step of 4 genes",
                           "peak_updates_per_s": 1024 * 4 * 2.4e9 / (7 * 4),
                           "frac": prof["sweeps"] * K / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * 2.4e9 / (7 * 4)),
-                          "branch_rate_bound_updates_per_s": 1024 * 4 / 18.8e-9,
                           "share_of_wall": prof["cd_ms"] / (dt * 1e3)},
             "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"],
             "setup_s": {"generate": t_gen, "upload_and_precompute": t_up},
