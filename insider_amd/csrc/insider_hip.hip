@@ -78,6 +78,11 @@ struct CovTables {   // per covariate, device
 struct insider_hip_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    // scheduling work that nothing but the next column solve needs (sweep keys -> gene order, the next iteration's sweep-order
+    // table) runs on a side stream, next to the row update, between two events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_cd_done = nullptr, ev_side_done = nullptr;
+    bool side_pending = false;
     int64_t n = 0, p = 0, ldn = 0, ldp = 0;
     int c = 0, SL = 0, SLP = 0;   // SL: rows of the stacked row factors = all levels of all covariates + m
     int m = 0, SLcat = 0;          // continuous covariates (columns of ctns_confounder) and the categorical level total
@@ -359,8 +364,10 @@ struct Timer {   // HIP-event pair around one launch on the library's stream (op
     }
 };
 
-int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode)
+int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode,
+                       hipStream_t stream = nullptr)
 {
+    if (!stream) stream = h->stream;
     if (h->order_rows < max_sweeps) {
         if (h->order) (void)hipFree(h->order);
         h->order = nullptr;
@@ -368,7 +375,7 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
         if (rc) return rc;
         h->order_rows = max_sweeps;
     }
-    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)max_sweeps * 64, 256)), dim3(256), 0, h->stream, seed, iter, K,
+    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)max_sweeps * 64, 256)), dim3(256), 0, stream, seed, iter, K,
                        max_sweeps, order_mode, K * 8, reg_kmax(K), h->order);
     KCHECK();
     return INSIDER_OK;
@@ -445,10 +452,14 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
 
 // column update from the statistics: elastic-net CD (alpha > 0) or ridge (alpha == 0), or evaluation only
 int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambda, double alpha, double tol,
-                     int checkpoint, bool timed, int outer_iter = -1)
+                     int checkpoint, bool timed, int outer_iter = -1, bool side = false)
 {
     const bool early = outer_iter >= 0 && outer_iter < insider_hip_handle::EARLY;
     const int NBLK = h->NB * (h->NB + 1) / 2, STAT = NBLK * 256;
+    if (h->side_pending) {   // the gene order / sweep-order table prepared on the side stream
+        HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_side_done, 0));
+        h->side_pending = false;
+    }
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
@@ -524,19 +535,34 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
     if ((rc = t.end(h, h->ev_cd))) return rc;
     if (solve && alpha != 0.0) {
         // schedule the next solve longest-first, genes of similar length sharing a wave (stable sort: deterministic)
+        hipStream_t st = h->stream;
+        if (side) {
+            HIPCHECK(hipEventRecord(h->ev_cd_done, h->stream));
+            HIPCHECK(hipStreamWaitEvent(h->side, h->ev_cd_done, 0));
+            st = h->side;
+        }
         size_t bytes = h->sort_tmp_bytes;
-        hipLaunchKernelGGL(k_sweep_key, dim3(cdiv(h->p, 256)), dim3(256), 0, h->stream, (const int *)h->sweeps, (int)h->p,
+        hipLaunchKernelGGL(k_sweep_key, dim3(cdiv(h->p, 256)), dim3(256), 0, st, (const int *)h->sweeps, (int)h->p,
                            (outer_iter < insider_hip_handle::EARLY || !h->have_perm) ? 1 : 0, h->sweep_key);
         KCHECK();
         HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweep_key, h->sweeps_sorted,
-                                                              h->gene_ids, h->gene_perm, (int)h->p, 0, 32, h->stream));
+                                                              h->gene_ids, h->gene_perm, (int)h->p, 0, 32, st));
         h->have_perm = true;
         if (early) {
             HIPCHECK(hipMemcpyAsync(h->perm_early[outer_iter], h->gene_perm, (size_t)h->p * sizeof(int),
-                                    hipMemcpyDeviceToDevice, h->stream));
+                                    hipMemcpyDeviceToDevice, st));
             h->have_early[outer_iter] = true;
         }
+        if (side) {   // the caller may add the next sweep-order table to the side stream, then closes it with side_close()
+            h->side_pending = true;
+        }
     }
+    return INSIDER_OK;
+}
+
+int side_close(insider_hip_handle *h)
+{
+    if (h->side_pending) HIPCHECK(hipEventRecord(h->ev_side_done, h->side));
     return INSIDER_OK;
 }
 
@@ -879,6 +905,9 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (h->Strain) (void)hipFree(h->Strain);
     if (h->Sheld) (void)hipFree(h->Sheld);
     if (h->cf_cnt) (void)hipFree(h->cf_cnt);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_cd_done) (void)hipEventDestroy(h->ev_cd_done);
+    if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -931,6 +960,9 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
 #define CH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { insider_hip_destroy(h); \
         return fail(e_ == hipErrorOutOfMemory ? INSIDER_ERR_ALLOC : INSIDER_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
     CH(hipStreamCreate(&h->stream));
+    CH(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    CH(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
+    CH(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
     // ---- X (gene-major lines of pitch ldn) and mask codes -------------------------------------------------
     CR(dmalloc(&h->X, (size_t)p * h->ldn));
     CR(dmalloc(&h->codes, (size_t)p * h->ldn));
@@ -1329,10 +1361,15 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         // ---- column step (:365-378) -------------------------------------------------------------------------------
         if ((rc = phase_R(h))) return rc;
         const int checkpoint = iter % 10 == 0;
-        if (alpha != 0.0)
+        if (alpha != 0.0 && iter == 0)   // later iterations: prepared on the side stream right after the previous solve
             if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
         if (masked) if ((rc = launch_col_stats(h, true))) return rc;
-        if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true, (int)iter))) return rc;  // :376
+        if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true, (int)iter, true))) return rc;  // :376
+        if (alpha != 0.0) {
+            if (iter < max_iter)
+                if ((rc = ensure_order_table(h, seed, iter + 1, K, h->max_sweeps, h->order_mode, h->side))) return rc;
+            if ((rc = side_close(h))) return rc;
+        }
         if (checkpoint) {                                                                       // :381-408
             if ((rc = launch_test_sse(h, masked, true))) return rc;
             pre_loss = loss;
@@ -1363,6 +1400,8 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     }
     if ((rc = download_factors(h, A, C, K))) return rc;
     if ((rc = check_fail_flag(h))) return rc;
+    HIPCHECK(hipStreamSynchronize(h->side));   // the gene orders kept for the next call
+    h->side_pending = false;
     {
         unsigned long long bins[256];
         HIPCHECK(hipMemcpy(bins, h->sweep_total, sizeof(bins), hipMemcpyDeviceToHost));
