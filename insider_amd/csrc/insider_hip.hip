@@ -83,6 +83,13 @@ struct insider_hip_handle {
     hipStream_t side = nullptr;
     hipEvent_t ev_cd_done = nullptr, ev_side_done = nullptr;
     bool side_pending = false;
+    // the weighted SYRK of the merged row update depends on C only: all covariates' level sums are formed on a second
+    // side stream while the main stream computes V, u and U'C
+    hipStream_t side2 = nullptr;
+    hipEvent_t ev_c_ready = nullptr;
+    std::vector<hipEvent_t> ev_w;
+    double *lvl_sum_all = nullptr;    // [SLcat][STAT + 2 KP + 2]: the level records of every covariate
+    bool w_ready = false;
     int64_t n = 0, p = 0, ldn = 0, ldp = 0;
     int c = 0, SL = 0, SLP = 0;   // SL: rows of the stacked row factors = all levels of all covariates + m
     int m = 0, SLcat = 0;          // continuous covariates (columns of ctns_confounder) and the categorical level total
@@ -162,7 +169,7 @@ constexpr int MM_SLAB = 128;  // rows per partial of the reduction products (ins
 void free_workspace(insider_hip_handle *h)
 {
     double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
-                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->Qheld, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
+                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->lvl_sum_all, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->Qheld, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->sweeps) (void)hipFree(h->sweeps);
@@ -226,6 +233,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
         if ((rc = dmalloc(&h->U, (size_t)h->p * LP))) return rc;
         if ((rc = dmalloc(&h->Ylvl, (size_t)std::max(h->max_L, 1) * KP))) return rc;
         if ((rc = dmalloc(&h->wpart, (size_t)std::max(h->max_items, 1) * STAT))) return rc;
+        if ((rc = dmalloc(&h->lvl_sum_all, (size_t)std::max(h->SLcat, 1) * (STAT + 2 * KP + 2)))) return rc;
         if ((rc = dmalloc(&h->Vlev, (size_t)h->p * h->SLP))) return rc;
         if ((rc = dmalloc(&h->Qheld, (size_t)h->p * KP))) return rc;
     }
@@ -634,6 +642,31 @@ int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
     return INSIDER_OK;
 }
 
+// merged row update: the weighted SYRK + level sums of every covariate (they depend on C and the static lists only) on the
+// second side stream, from the point where C is final; row_update() waits for its covariate's event
+int launch_wsyrk_side(insider_hip_handle *h)
+{
+    HIPCHECK(hipEventRecord(h->ev_c_ready, h->stream));
+    HIPCHECK(hipStreamWaitEvent(h->side2, h->ev_c_ready, 0));
+    for (int i = 0; i < h->c; ++i) {
+        const CovTables &ct = h->cov[i];
+        NB_DISPATCH(h->NB, {
+            constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
+            if (ct.nitems > 0)
+                hipLaunchKernelGGL((k_wsyrk<NB_, WPB_>), dim3(cdiv(ct.nitems, WPB_)), dim3(WPB_ * 64), 0, h->side2,
+                                   (const uint32_t *)ct.item_begin, (const uint32_t *)ct.item_end, ct.nitems,
+                                   (const int *)ct.wl_idx, (const double *)ct.wl_w, (const double *)h->C, (int64_t)h->p,
+                                   h->wpart);
+            hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), ct.L), dim3(256), 0, h->side2, (const double *)h->wpart,
+                               (const int *)ct.lvl_item_ptr, STAT_, h->lvl_sum_all + (size_t)h->lvl_off[i] * PLEN, PLEN);
+        });
+        KCHECK();
+        HIPCHECK(hipEventRecord(h->ev_w[i], h->side2));
+    }
+    h->w_ready = true;
+    return INSIDER_OK;
+}
+
 // one covariate's row update: categorical covariate i (optimize_row, src/optimize.cpp:139-198), or continuous
 // column j (optimize_continuous_v2, :76-137) when cont_col >= 0
 int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double lambda1)
@@ -685,18 +718,23 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
         KCHECK();
         // Y = U'C, the same reduction over genes as (S C')
         if (int rcy = launch_mm_reduce_kp(h, h->U, LP, h->C, (int)h->p, L, h->sc_part, h->Ylvl)) return rcy;
+        if (h->w_ready) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[i], 0));   // wsyrk + level sums came from side2
         NB_DISPATCH(h->NB, {
             constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
-            if (ct.nitems > 0)   // no held-out entry at all: every level sum is zero
-            hipLaunchKernelGGL((k_wsyrk<NB_, WPB_>), dim3(cdiv(ct.nitems, WPB_)), dim3(WPB_ * 64), 0, h->stream,
-                               (const uint32_t *)ct.item_begin, (const uint32_t *)ct.item_end, ct.nitems,
-                               (const int *)ct.wl_idx, (const double *)ct.wl_w, (const double *)h->C, (int64_t)h->p,
-                               h->wpart);
-            hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), L), dim3(256), 0, h->stream, (const double *)h->wpart,
-                               (const int *)ct.lvl_item_ptr, STAT_, h->lvl_sum, PLEN);
+            double *rec = h->w_ready ? h->lvl_sum_all + (size_t)h->lvl_off[i] * PLEN : h->lvl_sum;
+            if (!h->w_ready) {
+                if (ct.nitems > 0)   // no held-out entry at all: every level sum is zero
+                    hipLaunchKernelGGL((k_wsyrk<NB_, WPB_>), dim3(cdiv(ct.nitems, WPB_)), dim3(WPB_ * 64), 0, h->stream,
+                                       (const uint32_t *)ct.item_begin, (const uint32_t *)ct.item_end, ct.nitems,
+                                       (const int *)ct.wl_idx, (const double *)ct.wl_w, (const double *)h->C, (int64_t)h->p,
+                                       h->wpart);
+                hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), L), dim3(256), 0, h->stream, (const double *)h->wpart,
+                                   (const int *)ct.lvl_item_ptr, STAT_, rec, PLEN);
+            }
             hipLaunchKernelGGL(k_level_pack, dim3(L), dim3(256), 0, h->stream, (const double *)h->Ylvl,
                                (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
-                               (const int *)(h->lvl_count_all + h->lvl_off[i]), L, h->K, KP, STAT_, h->lvl_sum);
+                               (const int *)(h->lvl_count_all + h->lvl_off[i]), L, h->K, KP, STAT_, rec);
+            ra.part = rec;
             hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(L), dim3(64), 0, h->stream, ra);
         });
     } else {
@@ -906,6 +944,9 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (h->Sheld) (void)hipFree(h->Sheld);
     if (h->cf_cnt) (void)hipFree(h->cf_cnt);
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->ev_c_ready) (void)hipEventDestroy(h->ev_c_ready);
+    for (auto e : h->ev_w) (void)hipEventDestroy(e);
     if (h->ev_cd_done) (void)hipEventDestroy(h->ev_cd_done);
     if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -961,6 +1002,10 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
         return fail(e_ == hipErrorOutOfMemory ? INSIDER_ERR_ALLOC : INSIDER_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
     CH(hipStreamCreate(&h->stream));
     CH(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    CH(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    CH(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
+    h->ev_w.resize(c > 0 ? c : 1);
+    for (auto &e : h->ev_w) CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
     // ---- X (gene-major lines of pitch ldn) and mask codes -------------------------------------------------
@@ -1318,6 +1363,8 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     if ((rc = ensure_workspace(h, K))) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     clear_events(h);
+    h->w_ready = false;
+    h->side_pending = false;
     const int masked = tuning == 1;
     if ((rc = upload_factors(h, A, C, K))) return rc;
 
@@ -1349,12 +1396,14 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
         if ((rc = launch_row_prep(h, masked))) return rc;                                       // :332
         if (masked && !use_merged(h, masked)) if ((rc = launch_row_stats(h, true))) return rc;
+        if (use_merged(h, masked)) if ((rc = launch_wsyrk_side(h))) return rc;
         if (use_merged(h, masked)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
         for (int i = 0; i < h->c; ++i) {
             if ((rc = row_update(h, i, -1, masked, lambda1))) return rc;                        // :339
             if (use_merged(h, masked) && i + 1 < h->c)
                 if ((rc = launch_gene_v(h, h->lvl_off[i], h->lvl_off[i + 1]))) return rc;
         }
+        h->w_ready = false;
         if (inc_continuous)
             for (int j = 0; j < h->m; ++j)
                 if ((rc = row_update(h, 0, j, masked, lambda1))) return rc;                     // :340-351
@@ -1400,6 +1449,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     }
     if ((rc = download_factors(h, A, C, K))) return rc;
     if ((rc = check_fail_flag(h))) return rc;
+    HIPCHECK(hipStreamSynchronize(h->side2));
     HIPCHECK(hipStreamSynchronize(h->side));   // the gene orders kept for the next call
     h->side_pending = false;
     {
@@ -1465,6 +1515,7 @@ int insider_hip_optimize_row(insider_hip_handle *h, double *const *A, const doub
     if (lambda < 0) return fail(INSIDER_ERR_ARG, "lambda must be >= 0");
     HIPCHECK(hipSetDevice(h->device));
     if ((rc = ensure_workspace(h, K))) return rc;
+    h->w_ready = false;
     if ((rc = upload_factors(h, A, C, K))) return rc;
     if ((rc = launch_row_prep(h, tuning))) return rc;
     if (tuning == 1 && !use_merged(h, tuning)) if ((rc = launch_row_stats(h, false))) return rc;
