@@ -90,6 +90,9 @@ struct insider_hip_handle {
     std::vector<hipEvent_t> ev_w;
     double *lvl_sum_all = nullptr;    // [SLcat][STAT + 2 KP + 2]: the level records of every covariate
     bool w_ready = false;
+    double *gram_part2 = nullptr, *sc_part2 = nullptr;   // partial-sum buffers of the side-stream products
+    hipEvent_t ev_a_ready = nullptr, ev_qfull = nullptr;
+    bool qfull_pending = false;
     int64_t n = 0, p = 0, ldn = 0, ldp = 0;
     int c = 0, SL = 0, SLP = 0;   // SL: rows of the stacked row factors = all levels of all covariates + m
     int m = 0, SLcat = 0;          // continuous covariates (columns of ctns_confounder) and the categorical level total
@@ -169,7 +172,7 @@ constexpr int MM_SLAB = 128;  // rows per partial of the reduction products (ins
 void free_workspace(insider_hip_handle *h)
 {
     double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
-                       &h->sc_part, &h->lvl_part, &h->lvl_sum, &h->lvl_sum_all, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->Qheld, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
+                       &h->sc_part, &h->gram_part2, &h->sc_part2, &h->lvl_part, &h->lvl_sum, &h->lvl_sum_all, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->Qheld, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
     if (h->sweeps) (void)hipFree(h->sweeps);
@@ -234,6 +237,8 @@ int ensure_workspace(insider_hip_handle *h, int K)
         if ((rc = dmalloc(&h->Ylvl, (size_t)std::max(h->max_L, 1) * KP))) return rc;
         if ((rc = dmalloc(&h->wpart, (size_t)std::max(h->max_items, 1) * STAT))) return rc;
         if ((rc = dmalloc(&h->lvl_sum_all, (size_t)std::max(h->SLcat, 1) * (STAT + 2 * KP + 2)))) return rc;
+        if ((rc = dmalloc(&h->gram_part2, (size_t)std::max(h->gram_blocks_p, h->gram_blocks_n) * KP * KP))) return rc;
+        if ((rc = dmalloc(&h->sc_part2, (size_t)h->sc_blocks * h->SL * KP))) return rc;
         if ((rc = dmalloc(&h->Vlev, (size_t)h->p * h->SLP))) return rc;
         if ((rc = dmalloc(&h->Qheld, (size_t)h->p * KP))) return rc;
     }
@@ -300,11 +305,13 @@ int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *
 
 // ---- the small dense products on MFMA (insider_mm.hpp) -------------------------------------------------------------------
 // out[M x KP] = X[M x Kd] W[Kd x KP]   (W row-major with pitch KP)
-int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M, int Kd, const double *W, double *out)
+int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M, int Kd, const double *W, double *out,
+                      hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     NB_DISPATCH(h->NB, {
         (void)WPB_;
-        hipLaunchKernelGGL((k_mm_rows<NB_, false>), dim3(cdiv(cdiv(M, 16), 4), 1), dim3(256), 0, h->stream, X, ldx, M, Kd, W,
+        hipLaunchKernelGGL((k_mm_rows<NB_, false>), dim3(cdiv(cdiv(M, 16), 4), 1), dim3(256), 0, st, X, ldx, M, Kd, W,
                            h->KP, h->KP, out, (int64_t)h->KP, h->KP);
     });
     KCHECK();
@@ -313,24 +320,26 @@ int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M
 
 // part[slab][L][KP] = sum over slabs of MM_SLAB rows of X[m][l] Y[m][n], then the fixed-order sum over slabs -> out[L][KP]
 int launch_mm_reduce_kp(insider_hip_handle *h, const double *X, int64_t ldx, const double *Y, int M, int L, double *part,
-                        double *out)
+                        double *out, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     const int slabs = cdiv(M, MM_SLAB);
     NB_DISPATCH(h->NB, {
         (void)WPB_;
-        hipLaunchKernelGGL((k_mm_reduce<NB_>), dim3(slabs, cdiv(L, 16)), dim3(64), 0, h->stream, X, ldx, Y, (int64_t)h->KP, M,
+        hipLaunchKernelGGL((k_mm_reduce<NB_>), dim3(slabs, cdiv(L, 16)), dim3(64), 0, st, X, ldx, Y, (int64_t)h->KP, M,
                            MM_SLAB, L, h->KP, part, h->KP);
     });
     KCHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(L * h->KP, 16)), dim3(256), 0, h->stream, (const double *)part, slabs,
+    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(L * h->KP, 16)), dim3(256), 0, st, (const double *)part, slabs,
                        L * h->KP, out);
     KCHECK();
     return INSIDER_OK;
 }
 
-int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *out)
+int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *out, hipStream_t st = nullptr,
+                double *part = nullptr)
 {
-    return launch_mm_reduce_kp(h, F, h->KP, F, (int)rows, h->KP, h->gram_part, out);
+    return launch_mm_reduce_kp(h, F, h->KP, F, (int)rows, h->KP, part ? part : h->gram_part, out, st);
 }
 
 int launch_build_R(insider_hip_handle *h)
@@ -343,12 +352,22 @@ int launch_build_R(insider_hip_handle *h)
 }
 
 // R, R'R and Qfull from the current row factors (src/optimize.cpp:365-369 and the Xty of :222,235 via level sums)
-int phase_R(insider_hip_handle *h)
+// use_side: Qfull, which only the column solve reads, is formed on the side stream next to R'R and the column statistics
+int phase_R(insider_hip_handle *h, bool use_side = false)
 {
+    if (use_side) {
+        HIPCHECK(hipEventRecord(h->ev_a_ready, h->stream));
+        HIPCHECK(hipStreamWaitEvent(h->side, h->ev_a_ready, 0));
+        int rq = launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull, h->side);
+        if (rq) return rq;
+        HIPCHECK(hipEventRecord(h->ev_qfull, h->side));
+        h->qfull_pending = true;
+    }
     int rc = launch_build_R(h);
     if (rc) return rc;
     rc = launch_gram(h, h->R, h->n, h->RtR);
     if (rc) return rc;
+    if (use_side) return INSIDER_OK;
     return launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull);
 }
 
@@ -467,6 +486,10 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
     if (h->side_pending) {   // the gene order / sweep-order table prepared on the side stream
         HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_side_done, 0));
         h->side_pending = false;
+    }
+    if (h->qfull_pending) {
+        HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_qfull, 0));
+        h->qfull_pending = false;
     }
     Timer t;
     int rc = t.begin(h, timed);
@@ -648,6 +671,9 @@ int launch_wsyrk_side(insider_hip_handle *h)
 {
     HIPCHECK(hipEventRecord(h->ev_c_ready, h->stream));
     HIPCHECK(hipStreamWaitEvent(h->side2, h->ev_c_ready, 0));
+    // C'C and (S^train C') too (launch_row_prep): first read by k_level_reduce, i.e. after the wait for ev_w[0]
+    if (int rp = launch_gram(h, h->C, h->p, h->CCt, h->side2, h->gram_part2)) return rp;
+    if (int rp = launch_mm_reduce_kp(h, h->Strain, h->SLP, h->C, (int)h->p, h->SL, h->sc_part2, h->SC, h->side2)) return rp;
     for (int i = 0; i < h->c; ++i) {
         const CovTables &ct = h->cov[i];
         NB_DISPATCH(h->NB, {
@@ -946,6 +972,8 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
     if (h->ev_c_ready) (void)hipEventDestroy(h->ev_c_ready);
+    if (h->ev_a_ready) (void)hipEventDestroy(h->ev_a_ready);
+    if (h->ev_qfull) (void)hipEventDestroy(h->ev_qfull);
     for (auto e : h->ev_w) (void)hipEventDestroy(e);
     if (h->ev_cd_done) (void)hipEventDestroy(h->ev_cd_done);
     if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
@@ -1004,6 +1032,8 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     CH(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     CH(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     CH(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
+    CH(hipEventCreateWithFlags(&h->ev_a_ready, hipEventDisableTiming));
+    CH(hipEventCreateWithFlags(&h->ev_qfull, hipEventDisableTiming));
     h->ev_w.resize(c > 0 ? c : 1);
     for (auto &e : h->ev_w) CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
@@ -1365,6 +1395,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     clear_events(h);
     h->w_ready = false;
     h->side_pending = false;
+    h->qfull_pending = false;
     const int masked = tuning == 1;
     if ((rc = upload_factors(h, A, C, K))) return rc;
 
@@ -1394,9 +1425,9 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     while (iter <= max_iter) {                                                                  // :325
         if (h->verbose && iter % 10 == 0) printf("Iteration %u ---------------------------------\n", iter);
         // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
-        if ((rc = launch_row_prep(h, masked))) return rc;                                       // :332
+        if (use_merged(h, masked)) { if ((rc = launch_wsyrk_side(h))) return rc; }                // incl. the row prep
+        else if ((rc = launch_row_prep(h, masked))) return rc;                                  // :332
         if (masked && !use_merged(h, masked)) if ((rc = launch_row_stats(h, true))) return rc;
-        if (use_merged(h, masked)) if ((rc = launch_wsyrk_side(h))) return rc;
         if (use_merged(h, masked)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
         for (int i = 0; i < h->c; ++i) {
             if ((rc = row_update(h, i, -1, masked, lambda1))) return rc;                        // :339
@@ -1408,7 +1439,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
             for (int j = 0; j < h->m; ++j)
                 if ((rc = row_update(h, 0, j, masked, lambda1))) return rc;                     // :340-351
         // ---- column step (:365-378) -------------------------------------------------------------------------------
-        if ((rc = phase_R(h))) return rc;
+        if ((rc = phase_R(h, true))) return rc;
         const int checkpoint = iter % 10 == 0;
         if (alpha != 0.0 && iter == 0)   // later iterations: prepared on the side stream right after the previous solve
             if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
