@@ -1422,6 +1422,15 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     uint32_t iter = 0;
     unsigned long long sweeps_total = 0;
     HIPCHECK(hipMemsetAsync(h->sweep_total, 0, 256 * sizeof(unsigned long long), h->stream));
+    if (alpha != 0.0 && !h->have_perm && !h->have_early[0]) {   // no history on this handle: order the genes by sum of squares
+        size_t bytes = h->sort_tmp_bytes;
+        hipLaunchKernelGGL(k_yy_key, dim3(cdiv(h->p, 256)), dim3(256), 0, h->stream,
+                           (const double *)(masked ? h->yy_train : h->yy_all), (int)h->p, h->sweep_key);
+        KCHECK();
+        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweep_key, h->sweeps_sorted,
+                                                              h->gene_ids, h->gene_perm, (int)h->p, 0, 32, h->stream));
+        h->have_perm = true;
+    }
     while (iter <= max_iter) {                                                                  // :325
         if (h->verbose && iter % 10 == 0) printf("Iteration %u ---------------------------------\n", iter);
         // ---- row step: all covariates, Gauss-Seidel (:332-362) -------------------------------------------------
