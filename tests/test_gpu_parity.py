@@ -368,7 +368,8 @@ def test_handle_reuse_across_ranks_like_tune(oracle):
     # tune() keeps X/M resident and changes K / lambda / alpha between calls (R/insider.R:98-174)
     w = workloads.small(n=80, p=100, K=6)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
-    for K, lam, alpha in ((3, 1.0, 0.2), (6, 3.0, 0.5), (3, 0.1, 0.0)):
+    # K = 20 / 40 / 6 again: the workspace (statistics records, side-stream buffers) is rebuilt across MFMA block geometries
+    for K, lam, alpha in ((3, 1.0, 0.2), (6, 3.0, 0.5), (3, 0.1, 0.0), (20, 2.0, 0.4), (40, 2.0, 0.3), (6, 3.0, 0.5)):
         A0, C0 = workloads.init_factors(w.n_levels, K, w.p, seed=K)
         got = ds.optimize([a.copy(order="F") for a in A0], C0.copy(order="F"), K, lam, lam, alpha, max_iter=5, seed=2)
         ref = oracle.optimize(w.X, w.levels, w.n_levels, A0, C0, w.M_train, w.M_test, lam, lam, alpha, max_iter=5,
