@@ -17,3 +17,9 @@ def test_randomised_parity_sweep(script, seed):
     r = subprocess.run([sys.executable, os.path.join(HERE, script), CASES, str(seed)], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_repeated_calls_are_bitwise_reproducible_and_leak_free():
+    r = subprocess.run([sys.executable, os.path.join(HERE, "soak_determinism.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
