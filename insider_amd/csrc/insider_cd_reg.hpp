@@ -51,7 +51,7 @@ struct RegState {
     "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
     "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
-    "s_mov_b64 exec, %[ex]\n"
+    "s_mov_b64 exec, -1\n"
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
 #define REG_BLOCK2_LO(KK) \
     REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) "s_setpc_b64 vcc\n"
@@ -59,7 +59,6 @@ struct RegState {
     REG_BLOCK_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) "s_setpc_b64 vcc\n"
 #define REG_BLOCK1(KK) REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) "s_setpc_b64 vcc\n"
 #define REG_PROLOGUE                               \
-    "s_mov_b64 %[ex], exec\n"                      \
     "s_load_dwordx16 s[64:79], %[tb], 0x0\n"       \
     "s_load_dwordx16 s[80:95], %[tb], 0x40\n"      \
     "s_load_dwordx2 s[96:97], %[tb], 0x80\n"       \
@@ -110,11 +109,10 @@ struct RegState {
     {                                                                                                                    \
         double c, dn;                                                                                                    \
         int sk, p1, p2;                                                                                                  \
-        uint64_t ex;                                                                                                     \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
         asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                       \
                      : [h0] "+v"(S.h[0]), [h1] "+v"(S.h[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), [c] "=&v"(c),   \
-                       [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [ex] "=&s"(ex)                    \
+                       [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2)                                   \
                      : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(      \
                            S.inv[0]),                                                                                    \
                        [i1] "v"(S.inv[1]), [la] "s"(la), [tb] "s"(tb), [lm] "s"(lm)                                      \
@@ -138,11 +136,10 @@ __device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][1
 #if defined(__HIP_DEVICE_COMPILE__)
     double c, dn;
     int sk, p1, p2;
-    uint64_t ex;
     const uint64_t lm = 0x0001000100010001ull;
     asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16)
                  : [h0] "+v"(S.h[0]), [b0] "+v"(S.beta[0]), [c] "=&v"(c), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
-                   [p2] "=&s"(p2), [ex] "=&s"(ex)
+                   [p2] "=&s"(p2)
                  : REG_LIST_LO(REG_GA)[i0] "v"(S.inv[0]), [la] "s"(la), [tb] "s"(tb), [lm] "s"(lm)
                  : REG_CLOBBERS);
 #endif
@@ -228,7 +225,7 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
     uint64_t runm = __ballot(gene_ok);
     int sweep = 0, my_sweeps = 0;
     const uint32_t *tb = reinterpret_cast<const uint32_t *>(order + REG_ORDER_OFF);
-    while (runm != 0) {
+    while (runm != 0 && sweep < max_sweeps) {   // the sweep cap is the loop bound: genes still running then are parked below
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
         reg_sweep(S, G, la, tb);
         tb += ORDER_ROW / 4;
@@ -245,13 +242,11 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             s_w[64 * u] = w1;
         }
         const double dloss = row16_sum(fma(la, acc1, 0.5 * acc));
-        const uint64_t convm = __ballot(!(fabs(dloss) > tol));                             // :114
-        const uint64_t cand = sweep >= max_sweeps ? runm : (convm & runm);                  // genes that may stop now
+        const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
         if (cand != 0) {                                                                    // wave-uniform, rarely taken
             const bool mine = (cand >> lane) & 1ull;
-            bool finish = mine && sweep >= max_sweeps;
             bool anyv = false;
-            if (mine && !finish) {
+            if (mine) {
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
                     const bool viol = gene_ok && 16 * u + i < K && S.inv[u] == 0.0 && fabs(S.h[u]) > la;
@@ -259,7 +254,7 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
                     anyv = anyv || viol;
                 }
             }
-            if (mine && !finish && (__ballot(anyv) & rowmask) == 0) finish = true;        // :120-121
+            const bool finish = mine && (__ballot(anyv) & rowmask) == 0;                    // :120-121
             if (finish) {   // park the row: zero increments from now on
                 my_sweeps = sweep;
 #pragma unroll
@@ -271,6 +266,11 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             }
             runm &= ~__ballot(finish);
         }
+    }
+    if ((runm >> lane) & 1ull) {   // stopped by the sweep cap
+        my_sweeps = sweep;
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) s_out[64 * u] = S.beta[u];
     }
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) beta[u] = (gene_ok && 16 * u + i < K) ? s_out[64 * u] : 0.0;
