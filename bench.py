@@ -164,6 +164,25 @@ def main():
         dt = float(t.item())
     assert res["iters"] == args.steps, (res["iters"], args.steps)
 
+    def copy_bandwidth():
+        """Device-to-device copy of 2 GiB (read + write counted), best of 5: what this box's HBM delivers to a plain copy,
+        next to the 8 TB/s the roofline is priced against (SURVEY.md 8d asks for both)."""
+        try:
+            a = torch.empty(1 << 31, dtype=torch.uint8, device="cuda")
+            b = torch.empty_like(a)
+            best = 0.0
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                b.copy_(a)
+                e1.record()
+                torch.cuda.synchronize()
+                best = max(best, 2.0 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            del a, b
+            return best
+        except Exception:
+            return None
+
     if rank == 0:
         gram_ms = (prof["col_stats_ms"] / max(prof["col_stats_launches"], 1))
         # algorithmic bytes / flops of ONE launch of the masked Gram/XtY kernel over this rank's genes
@@ -203,6 +222,7 @@ def main():
                                    "k_list_stats (masked Gram/XtY complement statistics over the held-out lists, column side)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_GBs": copy_bandwidth() if world == 1 else None,
                          "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],
                          # flops of the masked reduction as SURVEY 8d counts them (2 f n p (T + K)), not the flops executed
                          "algorithmic_fp64_tflops": fl / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
