@@ -193,8 +193,13 @@ def test_ridge_column_kernel_instantiations(oracle, K, tuning):
                                 # > 2048 held-out samples per gene: index staging overflows, several 512-entry tiles
                                 dict(level_counts=(5, 3), n=3000, p=24, K=4, f=0.8),
                                 # ~400 held-out entries per (level, level) cell: the one-byte pair counts overflow
-                                dict(level_counts=(2, 2), n=2000, p=16, K=4, f=0.8)],
-                         ids=["one-cov", "300-levels", "five-cov", "long-groups", "2400-held-out-per-gene", "count-overflow"])
+                                dict(level_counts=(2, 2), n=2000, p=16, K=4, f=0.8),
+                                # 21 table rows: six k-steps of the count product, two count dwords per lane
+                                dict(level_counts=(9, 8, 7, 6), n=700, p=60, K=9, f=0.2),
+                                # 36 table rows: beyond the pair-count form (look-up form runs instead)
+                                dict(level_counts=(12, 12, 12, 12), n=800, p=50, K=5, f=0.2)],
+                         ids=["one-cov", "300-levels", "five-cov", "long-groups", "2400-held-out-per-gene", "count-overflow",
+                              "21-table-rows", "36-table-rows"])
 def test_statistics_paths_on_odd_covariate_structures(oracle, kw, paths):
     w = workloads.small(seed=91, **kw)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
@@ -205,7 +210,7 @@ def test_statistics_paths_on_odd_covariate_structures(oracle, kw, paths):
     ds.close()
     assert pr["row_merged"] == (paths != "lists") and pr["col_factored"] == (paths != "lists")
     if paths == "pair":   # the pair-count form needs every count to fit one byte; else the look-up form runs
-        assert pr["col_pair"] == (kw["n"] != 2000)
+        assert pr["col_pair"] == (kw["n"] not in (2000, 800))
     ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
                           max_iter=10, seed=4)
     for i, a in enumerate(ref["row_matrices"]):
