@@ -46,13 +46,15 @@ struct ColFacArgs {
 };
 
 // Gc = M + M' for the lower blocks, XtX_j = R'R - Gc; qc and the sum of squares go into row KP - 1 of the record
+// rtr: R'R (global, or a copy in LDS); qh / ss: this lane's Qheld entries (column 16 bj + c16) and the sum of squares,
+// loaded by the caller (early, so that their latency hides behind the MFMAs)
 template <int NB>
-__device__ __forceinline__ void cf_store(d4 (&acc)[NB][NB], double *tr, const ColFacArgs &a, int j, int lane)
+__device__ __forceinline__ void cf_store(d4 (&acc)[NB][NB], double *tr, const ColFacArgs &a, int j, int lane,
+                                         const double *rtr, const double (&qh)[NB], double ss)
 {
     constexpr int KP = Geo<NB>::KP;
     const int g4 = lane >> 4, c16 = lane & 15;
     double *out = a.stat + (size_t)j * Geo<NB>::STAT;
-    const double ss = a.yy_all[j] - a.yy_train[j];
     int blk = 0;
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
@@ -67,12 +69,12 @@ __device__ __forceinline__ void cf_store(d4 (&acc)[NB][NB], double *tr, const Co
             for (int r = 0; r < 4; ++r) {
                 const int ra = 16 * bi + g4 + 4 * r, cb = 16 * bj + c16;
                 res[r] = acc[bi][bj][r] + tr[c16 * 17 + g4 + 4 * r];
-                if (ra < a.K && cb < a.K) res[r] = a.RtR[ra * KP + cb] - res[r];
+                if (ra < a.K && cb < a.K) res[r] = rtr[ra * KP + cb] - res[r];
             }
             wave_sync();
             if (bi == NB - 1 && g4 == 3) {   // global row KP - 1 = local row 15 = register 3 of lanes 48..63
                 const int col = 16 * bj + c16;
-                res[3] = col < a.K ? a.Qheld[(size_t)j * KP + col] : (col == KP - 1 ? ss : 0.0);
+                res[3] = col < a.K ? qh[bj] : (col == KP - 1 ? ss : 0.0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[blk * 256 + (g4 + 4 * r) * 16 + c16] = res[r];
@@ -173,7 +175,10 @@ __global__ void __launch_bounds__(WPB * 64) k_col_factored(ColFacArgs a)
         }
         wave_sync();
     }
-    cf_store<NB>(acc, tr, a, j, lane);
+    double qh[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) qh[bb] = a.Qheld[(size_t)j * KP + 16 * bb + (lane & 15)];
+    cf_store<NB>(acc, tr, a, j, lane, a.RtR, qh, a.yy_all[j] - a.yy_train[j]);
     (void)NBLK;
 }
 
@@ -197,10 +202,12 @@ template <int NB, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
 {
     constexpr int KP = Geo<NB>::KP;
-    extern __shared__ double s_cp[];   // per wave: 16 x 17 transpose scratch | table rows [4 nsteps][KP], zero padded
+    extern __shared__ double s_cp[];   // per wave: 16 x 17 transpose scratch | R'R [KP][KP] | table rows [4 nsteps][KP], zero padded
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *tr = s_cp + (size_t)w * 16 * 17;
-    double *tabs = s_cp + (size_t)WPB * 16 * 17;
+    double *rtr = s_cp + (size_t)WPB * 16 * 17;
+    double *tabs = rtr + KP * KP;
+    for (int i = threadIdx.x; i < KP * KP; i += WPB * 64) rtr[i] = a.RtR[i];
     for (int i = threadIdx.x; i < 4 * a.nsteps * KP; i += WPB * 64) {
         const int r = i / KP, k = i % KP;
         const int q = r < a.tab_skip_lo ? r : r + a.tab_skip_n;
@@ -210,6 +217,10 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
     const int j = blockIdx.x * WPB + w;
     if (j >= a.p) return;
     const int g4 = lane >> 4, c16 = lane & 15;
+    double qh[NB];                       // the epilogue's operands, requested now
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) qh[bb] = a.Qheld[(size_t)j * KP + 16 * bb + c16];
+    const double ss = a.yy_all[j] - a.yy_train[j];
     const int bpl = a.nsteps <= 4 ? 4 : 8;   // count bytes per lane and block
     const double *tbl = tabs + g4 * KP + c16;   // B operand of k-step s, block bb: tbl[4 s KP + 16 bb]
     d4 acc[NB][NB];
@@ -281,7 +292,7 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
                 }
         }
     }
-    cf_store<NB>(acc, tr, a, j, lane);
+    cf_store<NB>(acc, tr, a, j, lane, rtr, qh, ss);
 }
 
 // The dense pair counts of every gene (once per data set): one wave per gene, LDS histogram per covariate position.

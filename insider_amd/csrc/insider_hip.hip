@@ -459,7 +459,7 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
             a.cnt = h->cf_cnt;
             NB_DISPATCH(h->NB, {
                 (void)WPB_;
-                const size_t lds = ((size_t)4 * 16 * 17 + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
+                const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
                 hipLaunchKernelGGL((k_col_paircnt<NB_, 4>), dim3(cdiv(h->p, 4)), dim3(256), lds, h->stream, a);
             });
         } else {
