@@ -28,12 +28,13 @@ extern "C" {
 
 #define INSIDER_OK 0
 #define INSIDER_ERR_ARG 1        /* bad argument (tuning not in {0,1}, level ids not 1..L_i, K out of range, ...) */
-#define INSIDER_ERR_SOLVE 2      /* a ridge normal-equation system was not positive definite */
+#define INSIDER_ERR_SOLVE 2      /* a normal-equation system is singular to working precision (neither route of
+                                    solve(..., likely_sympd) could solve it) */
 #define INSIDER_ERR_ALLOC 3      /* host or device allocation failed */
 #define INSIDER_ERR_HIP 4        /* HIP runtime error (message has the call) */
 #define INSIDER_ERR_NO_DEVICE 5  /* no HIP device / extension unusable: no fallback exists */
 #define INSIDER_ERR_UNSUPPORTED 6 /* K > 63, n or p >= 2^23, ... */
-#define INSIDER_ERR_COMM 7       /* the all-reduce callback reported failure */
+#define INSIDER_ERR_COMM 7       /* RCCL or the all-reduce callback reported failure, or world > 1 has neither */
 
 /* Largest latent dimension the kernels support (K + 1 augmented column <= 64). */
 #define INSIDER_MAX_K 63
@@ -89,6 +90,18 @@ void insider_hip_destroy(insider_hip_handle *h);
 int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, int world, insider_allreduce_fn fn,
                           void *user);
 
+/* In-library RCCL (the collective BASELINE.json's north star names): the per-covariate level equations and the loss
+ * terms are summed over the gene-sharded ranks by ncclAllReduce ENQUEUED ON THE LIBRARY'S OWN STREAM, between the kernels
+ * that produce and consume them; the callback of insider_hip_set_shard() is then not used (it remains as the fallback
+ * for hosts that bring their own communicator).  Rank 0 obtains an id with insider_hip_comm_unique_id(), the host
+ * distributes those INSIDER_COMM_ID_BYTES bytes to every rank by any means (insider_amd/dist.py: one broadcast over
+ * torch.distributed), and every rank calls insider_hip_comm_init() after insider_hip_set_shard(h, offset, rank, world,
+ * NULL, NULL).  Collective call: returns when all `world` ranks have joined.  The communicator is destroyed with the
+ * handle. */
+#define INSIDER_COMM_ID_BYTES 128
+int insider_hip_comm_unique_id(void *out, int out_bytes);
+int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank, int world);
+
 /* Options: "max_sweeps" (per elastic-net subproblem, default 10000), "order_mode" (0 = hashed random order of
  * include/insider_perm.h, 1 = cyclic), "profile" (1 = time the statistics / solve kernels with HIP events),
  * "verbose" (1 = print the reference's per-checkpoint lines to stdout), "cd_variant" (elastic-net sweep kernel for
@@ -124,7 +137,18 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
                          uint32_t max_iter, uint64_t seed, double *out_train_rmse, double *out_test_rmse,
                          double *out_loss, double *traj, int traj_cap, int *out_traj_rows, int *out_iters);
 
-/* One-shot form with the reference's 16 logical arguments (create + optimize + destroy). */
+/* One-shot form with the reference's 16 logical arguments (create + optimize + destroy): the direct replacement of
+ * .Call(`_insider_optimize`, ...) (src/RcppExports.cpp:87-110, R/RcppExports.R:20-22) that r/insider_hip_shim.c binds.
+ *   ctns / m     ctns_confounder (n x m column-major); read only when inc_continuous = 1, exactly as the reference
+ *                ignores it otherwise (src/optimize.cpp:276-291); A then carries c + 1 pointers (the last one m x K)
+ *   device       HIP device ordinal
+ * insider_hip_optimize_oneshot() is the same for categorical covariates on device 0. */
+int insider_hip_optimize_oneshot_ex(const double *X, int64_t n, int64_t p, double *const *A, double *C,
+                                    const int32_t *levels, int c, const int32_t *n_levels, const double *ctns, int m,
+                                    const uint8_t *M_train, const uint8_t *M_test, int inc_continuous, int K,
+                                    double lambda1, double lambda2, double alpha, int tuning, double global_tol,
+                                    double sub_tol, uint32_t max_iter, uint64_t seed, int device, double *out_train_rmse,
+                                    double *out_test_rmse, double *out_loss);
 int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *const *A, double *C,
                                  const int32_t *levels, int c, const int32_t *n_levels, const uint8_t *M_train,
                                  const uint8_t *M_test, int inc_continuous, int K, double lambda1, double lambda2,
@@ -138,10 +162,11 @@ int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *
  * insider_hip_optimize_row — one row update of covariate `cov` (src/optimize.cpp:139-198 as called at :339): the
  *   residual is X minus the contributions of every other covariate as passed in A; A[cov] (L_cov x K) is replaced by
  *   the per-level solutions of (sum_{r in level}(CC' - C_z C_z') + lambda I) a = sum_r C_nz resid[r, nz] (tuning = 1)
- *   or (|level| CC' + lambda I) a = sum_r C resid[r, :]' (tuning = 0).  lambda >= 0: lambda = 0 with the other
- *   factors zero is fit_interaction()'s arithmetic (src/fit_interaction.cpp:10-90, which applies no ridge term).
+ *   or (|level| CC' + lambda I) a = sum_r C resid[r, :]' (tuning = 0).  lambda = 0 with the other
+ *   factors zero is fit_interaction()'s arithmetic (src/fit_interaction.cpp:10-90, which applies no ridge term).  The
+ *   solve is solve(..., likely_sympd): a system that is not positive definite (lambda <= 0) takes the general route.
  *   cov in [c, c+m) with inc_continuous = 1 updates row cov-c of the continuous factor (optimize_continuous_v2,
- *   src/optimize.cpp:76-137).  Returns INSIDER_ERR_SOLVE when a level's system is not positive definite.
+ *   src/optimize.cpp:76-137).  Returns INSIDER_ERR_SOLVE when a level's system is singular to working precision.
  * insider_hip_optimize_col — one column update (src/optimize.cpp:200-253 as called at :376): every gene's
  *   elastic-net regression of X[:, j] on the row factor R = sum_i Z_i A_i over its training entries, warm-started
  *   at C[:, j] (alpha > 0), or the ridge solve (alpha == 0); C is updated in place.  `iter` picks the sweep-order
@@ -165,6 +190,21 @@ int insider_hip_optimize_col(insider_hip_handle *h, double *const *A, double *C,
 int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob,
                           double lambda, double alpha, double tol, uint64_t seed, uint32_t iter, int order_mode,
                           int max_sweeps, int device, double *beta_out, int32_t *sweeps_out);
+/* The same solver with the reference's eight arguments, one subproblem (.Call `_insider_strong_coordinate_descent`,
+ * src/RcppExports.cpp:35-50: X, y, wstart, lambda, alpha, XtX, Xty, tol): X is m x K column-major, y has m entries.
+ * XtX / Xty may be NULL: they are then formed on the device as X'X and X'y (what the reference's callers pass,
+ * src/optimize.cpp:219-222,234-235).  When they are given, X and y may be NULL. */
+int insider_hip_strong_cd_xy(const double *X, const double *y, int64_t m, int K, const double *wstart, double lambda,
+                             double alpha, const double *XtX, const double *Xty, double tol, uint64_t seed, uint32_t iter,
+                             int order_mode, int max_sweeps, int device, double *beta_out, int32_t *sweeps_out);
+
+/* solve(A, b, solve_opts::likely_sympd) as the row / ridge updates use it (src/optimize.cpp:175,190,226,240;
+ * src/fit_interaction.cpp:54), batched: nsys systems of K x K (column-major) with one right-hand side each.  The
+ * positive-definite route (Cholesky) first; when a pivot is not positive, the general route (Gaussian elimination with
+ * partial pivoting) — Armadillo's documented behaviour.  route (optional, nsys ints): 0 = Cholesky, 1 = general, -1 =
+ * singular (status INSIDER_ERR_SOLVE).  Stand-alone for parity tests of the fallback; the updates call the same
+ * device code. */
+int insider_hip_solve_sympd(const double *A, const double *b, int K, int64_t nsys, int device, double *x, int32_t *route);
 
 /*
  * The masked Gram / XtY reductions on their own (for parity tests and profiling).
@@ -185,8 +225,14 @@ int insider_hip_masked_gram_rows(insider_hip_handle *h, const double *C, int K, 
  *  merged row update, 4 = the factored column statistics ran in their pair-count form)}. */
 int insider_hip_get_profile(insider_hip_handle *h, double *out12);
 
+/* Facts about the handle that measurement code needs (bench.py's roofline): "col_stats_path" (0 = per-entry lists, 1 =
+ * look-up form, 2 = pair-count form, as the cost model / options chose for the current K), "col_mfma_per_gene"
+ * (v_mfma_f64_16x16x4 instructions the column-side statistics kernel issues per gene), "row_merged", "col_entries",
+ * "row_entries" (padded held-out list lengths), "lists_bytes", "pair_count_bytes_per_gene", "stat_doubles", "kp". */
+int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out);
+
 /* Diagnostics: per-gene sweep counts of the last column update (p ints), and the HIP-event time in ms of the
- * kernel launched by the calling process's last insider_hip_strong_cd(). */
+ * kernel launched by the calling THREAD's last insider_hip_strong_cd() / _xy(). */
 int insider_hip_get_sweeps(insider_hip_handle *h, int32_t *out);
 double insider_hip_last_cd_ms(void);
 

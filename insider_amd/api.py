@@ -164,6 +164,17 @@ class InsiderData:
                     col_factored=bool(int(out[11]) & 1), row_merged=bool(int(out[11]) & 2),
                     col_pair=bool(int(out[11]) & 4))
 
+    def info(self, name):
+        """A fact about the handle (insider_hip_get_info): "col_stats_path", "col_mfma_per_gene", ..."""
+        out = C.c_double()
+        _lib.check(_lib.load().insider_hip_get_info(self._h, name.encode(), C.byref(out)))
+        return out.value
+
+    def comm_init(self, unique_id, rank, world):
+        """Join the in-library RCCL communicator (insider_hip_comm_init) after set_shard(); collective over all ranks."""
+        buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _lib.check(_lib.load().insider_hip_comm_init(self._h, buf, int(rank), int(world)))
+
     def sweeps(self):
         """Per-gene sweep counts of the last column update."""
         out = np.zeros(self.p, dtype=np.int32)
@@ -188,38 +199,93 @@ class InsiderData:
 def optimize(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, train_indicator, test_indicator,
              inc_continuous, latent_dim, lambda1=1.0, lambda2=1.0, alpha=0.1, tuning=1, global_tol=1e-10, sub_tol=1e-5,
              max_iter=10000, seed=DEFAULT_SEED, device=0):
-    """optimize() of R/RcppExports.R:20-22 (src/optimize.cpp:255-422): one-shot upload + fit.
+    """optimize() of R/RcppExports.R:20-22 (src/optimize.cpp:255-422): one-shot upload + fit, through
+    ``insider_hip_optimize_oneshot_ex`` — the symbol r/insider_hip_shim.c binds for the R package.
 
     Returns dict(row_matrices, column_factor, train_rmse, test_rmse, loss) like the reference's List (:417-421);
-    float64 Fortran-ordered ``cfd_factors`` / ``column_factor`` arrays are also updated in place.
+    float64 Fortran-ordered ``cfd_factors`` / ``column_factor`` arrays are also updated in place (:283-284).
     """
     if tuning not in (0, 1):
         raise InsiderError(_lib.ERR_ARG, "Parameter tuning should be either 0 or 1!")
     if inc_continuous not in (0, 1):
         raise InsiderError(_lib.ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.")
-    ds = InsiderData(data, cfd_indicators, train_indicator, test_indicator, device=device,
-                     ctns_confounder=ctns_confounder if inc_continuous == 1 else None)
-    try:
-        return ds.optimize(cfd_factors, column_factor, latent_dim, lambda1, lambda2, alpha, tuning, global_tol, sub_tol,
-                           max_iter, seed, inc_continuous)
-    finally:
-        ds.close()
+    lib = _lib.load()
+    X = _lib.f64(data)
+    n, p = X.shape
+    K = int(latent_dim)
+    lev = np.asfortranarray(np.asarray(cfd_indicators).reshape(n, -1), dtype=np.int32)
+    c = lev.shape[1]
+    n_levels = np.ascontiguousarray([len(np.unique(lev[:, i])) for i in range(c)], dtype=np.int32)   # R/insider.R:107
+    Mtr = np.asfortranarray(train_indicator, dtype=np.uint8)
+    Mte = np.asfortranarray(test_indicator, dtype=np.uint8)
+    if Mtr.shape != (n, p) or Mte.shape != (n, p):
+        raise InsiderError(_lib.ERR_ARG, "indicator shape must match data")
+    if inc_continuous == 1:
+        Z = _lib.f64(np.asarray(ctns_confounder, dtype=np.float64).reshape(n, -1))
+        m, zp = Z.shape[1], _lib.ptr(Z)
+    else:
+        m, zp = 0, None
+    shapes = [int(L) for L in n_levels] + ([m] if inc_continuous else [])
+    if len(cfd_factors) != len(shapes):
+        raise InsiderError(_lib.ERR_ARG, f"expected {len(shapes)} row-factor matrices, got {len(cfd_factors)}")
+    A = []
+    for i, a in enumerate(cfd_factors):
+        a = np.asarray(a)
+        if a.shape != (shapes[i], K):
+            raise InsiderError(_lib.ERR_ARG, f"cfd_factors[{i}] must be {shapes[i]} x {K}")
+        A.append(a if (a.dtype == np.float64 and a.flags.f_contiguous) else _lib.f64(a).copy(order="F"))
+    Cm = np.asarray(column_factor)
+    if Cm.shape != (K, p):
+        raise InsiderError(_lib.ERR_ARG, f"column_factor must be {K} x {p}")
+    Cw = Cm if (Cm.dtype == np.float64 and Cm.flags.f_contiguous) else _lib.f64(Cm).copy(order="F")
+    Aptrs = (C.POINTER(C.c_double) * len(A))(*[_lib.ptr(a) for a in A])
+    tr, te, lo = C.c_double(), C.c_double(), C.c_double()
+    _lib.check(lib.insider_hip_optimize_oneshot_ex(_lib.ptr(X), n, p, Aptrs, _lib.ptr(Cw), _lib.ptr(lev, C.c_int32), c,
+                                                   _lib.ptr(n_levels, C.c_int32), zp, m, _lib.ptr(Mtr, C.c_uint8),
+                                                   _lib.ptr(Mte, C.c_uint8), int(inc_continuous), K, float(lambda1),
+                                                   float(lambda2), float(alpha), int(tuning), float(global_tol),
+                                                   float(sub_tol), int(max_iter), int(seed), int(device), C.byref(tr),
+                                                   C.byref(te), C.byref(lo)))
+    for src, dst in zip(A, cfd_factors):
+        if src is not dst and isinstance(dst, np.ndarray):
+            dst[...] = src
+    if Cw is not column_factor and isinstance(column_factor, np.ndarray):
+        column_factor[...] = Cw
+    return dict(row_matrices={f"factor{i}": a.copy() for i, a in enumerate(A)}, column_factor=Cw.copy(),
+                train_rmse=tr.value, test_rmse=te.value, loss=lo.value)
 
 
-def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol=1e-5, seed=DEFAULT_SEED, it=0,
+def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX=None, Xty=None, tol=1e-5, seed=DEFAULT_SEED, it=0,
                               order_mode=0, max_sweeps=10000, device=0, return_sweeps=False):
     """strong_coordinate_descent() of R/RcppExports.R:8-10 (src/coordinate_descent.cpp:56-127).
 
-    ``X`` and ``y`` are accepted for signature parity; the solver works in covariance form on ``XtX`` / ``Xty``
-    (which the reference's signature already carries).  Batched use: pass XtX of shape (B, K, K) and Xty / wstart of
-    shape (B, K).
+    Single problem (the reference's signature): ``X`` m x K, ``y`` m; ``XtX`` / ``Xty`` are formed on the device as X'X
+    and X'y when they are not given (``insider_hip_strong_cd_xy``).  Batched use: XtX of shape (B, K, K), Xty / wstart
+    of shape (B, K); X and y are then not read (covariance form).
     """
+    w = np.ascontiguousarray(wstart, dtype=np.float64)
+    if XtX is None or Xty is None or np.ndim(Xty) == 1:
+        if X is None and (XtX is None or Xty is None):
+            raise InsiderError(_lib.ERR_ARG, "pass (X, y), or XtX and Xty")
+        K = int(w.shape[0])
+        Xf = _lib.f64(X) if X is not None else None
+        yf = np.ascontiguousarray(y, dtype=np.float64) if y is not None else None
+        if Xf is not None and (Xf.ndim != 2 or Xf.shape[1] != K or yf is None or yf.shape != (Xf.shape[0],)):
+            raise InsiderError(_lib.ERR_ARG, "X must be m x K and y of length m")
+        G = _lib.f64(XtX) if XtX is not None else None
+        q = np.ascontiguousarray(Xty, dtype=np.float64) if Xty is not None else None
+        if (G is not None and G.shape != (K, K)) or (q is not None and q.shape != (K,)):
+            raise InsiderError(_lib.ERR_ARG, "XtX must be K x K and Xty of length K")
+        beta = np.zeros(K)
+        sw = np.zeros(1, dtype=np.int32)
+        _lib.check(_lib.load().insider_hip_strong_cd_xy(
+            _lib.ptr(Xf) if Xf is not None else None, _lib.ptr(yf) if yf is not None else None,
+            int(Xf.shape[0]) if Xf is not None else 0, K, _lib.ptr(w), float(lambda_), float(alpha),
+            _lib.ptr(G) if G is not None else None, _lib.ptr(q) if q is not None else None, float(tol), int(seed), int(it),
+            int(order_mode), int(max_sweeps), int(device), _lib.ptr(beta), _lib.ptr(sw, C.c_int32)))
+        return (beta, int(sw[0])) if return_sweeps else beta
     G = np.ascontiguousarray(XtX, dtype=np.float64)
     q = np.ascontiguousarray(Xty, dtype=np.float64)
-    w = np.ascontiguousarray(wstart, dtype=np.float64)
-    single = G.ndim == 2
-    if single:
-        G, q, w = G[None], q[None], w[None]
     B, K = q.shape
     if G.shape != (B, K, K) or w.shape != (B, K):
         raise InsiderError(_lib.ERR_ARG, "XtX must be (B,K,K) and Xty/wstart (B,K)")
@@ -229,9 +295,29 @@ def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol=1e-5, 
                                                  float(alpha), float(tol), int(seed), int(it),
                                                  int(order_mode), int(max_sweeps), int(device), _lib.ptr(beta),
                                                  _lib.ptr(sw, C.c_int32)))
-    if single:
-        beta, sw = beta[0], int(sw[0])
     return (beta, sw) if return_sweeps else beta
+
+
+def solve_sympd(A, b, device=0, return_route=False):
+    """solve(A, b, solve_opts::likely_sympd) (src/optimize.cpp:175,190,226,240), batched: A (B, K, K) or (K, K), b (B, K)
+    or (K,).  Cholesky first, Gaussian elimination with partial pivoting when A is not positive definite."""
+    Am = np.asarray(A, dtype=np.float64)
+    bm = np.asarray(b, dtype=np.float64)
+    single = Am.ndim == 2
+    if single:
+        Am, bm = Am[None], bm[None]
+    B, K = bm.shape
+    if Am.shape != (B, K, K):
+        raise InsiderError(_lib.ERR_ARG, "A must be (B,K,K) and b (B,K)")
+    Af = np.ascontiguousarray(np.transpose(Am, (0, 2, 1)))     # every block column-major
+    bf = np.ascontiguousarray(bm)
+    x = np.zeros((B, K))
+    route = np.zeros(B, dtype=np.int32)
+    _lib.check(_lib.load().insider_hip_solve_sympd(_lib.ptr(Af), _lib.ptr(bf), K, B, int(device), _lib.ptr(x),
+                                                   _lib.ptr(route, C.c_int32)))
+    if single:
+        x, route = x[0], int(route[0])
+    return (x, route) if return_route else x
 
 
 # ---------------------------------------------------------------------------------------------------------------

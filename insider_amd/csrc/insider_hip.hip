@@ -8,6 +8,7 @@
 #include "insider_kernels.hpp"
 
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -26,7 +27,7 @@ using namespace insider;
 namespace {
 
 thread_local std::string g_err;
-double g_last_cd_ms = 0.0;
+thread_local double g_last_cd_ms = 0.0;   // per calling thread: the ABI is re-entrant per handle / per thread
 
 int fail(int code, const std::string &msg)
 {
@@ -55,6 +56,24 @@ int dmalloc(T **p, size_t count)
     HIPCHECK(hipMalloc((void **)p, count * sizeof(T)));
     return INSIDER_OK;
 }
+
+// device temporaries of the handle-less entry points: freed on every exit path
+struct DevBufs {
+    std::vector<void *> ptrs;
+    std::vector<hipEvent_t> events;
+    ~DevBufs()
+    {
+        for (void *q : ptrs) if (q) (void)hipFree(q);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+    template <typename T>
+    int alloc(T **p, size_t count)
+    {
+        int rc = dmalloc(p, count);
+        if (rc == INSIDER_OK) ptrs.push_back((void *)*p);
+        return rc;
+    }
+};
 
 struct CovTables {   // per covariate, device
     int L = 0, nchunks = 0;
@@ -158,6 +177,7 @@ struct insider_hip_handle {
     int rank = 0, world = 1;
     insider_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    ncclComm_t comm = nullptr;     // RCCL communicator over the gene-sharded ranks (insider_hip_comm_init); owned
     // options
     int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0, cd_variant = 0, force_allreduce = 0;
     // profile of the last optimize()
@@ -251,7 +271,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     h->stage_count = (size_t)std::max<int64_t>(std::max<int64_t>(h->p, h->n), h->SL) * KP;
     if ((rc = dmalloc(&h->stage, h->stage_count))) return rc;
     if ((rc = dmalloc(&h->sweeps, (size_t)h->p))) return rc;
-    if ((rc = dmalloc(&h->failflag, 1))) return rc;
+    if ((rc = dmalloc(&h->failflag, 2))) return rc;   // [0] a system was singular, [1] ridge genes wait for the general route
     if ((rc = dmalloc(&h->sweep_total, 256))) return rc;
     if ((rc = dmalloc(&h->gene_ids, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
@@ -274,7 +294,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     // pad genes of the transposed layout index rows p..ldp-1
     HIPCHECK(hipMemsetAsync(h->C, 0, (size_t)std::max<int64_t>(h->p, h->ldp) * KP * sizeof(double), h->stream));
     HIPCHECK(hipMemsetAsync(h->R, 0, (size_t)h->n * KP * sizeof(double), h->stream));
-    HIPCHECK(hipMemsetAsync(h->failflag, 0, sizeof(int), h->stream));
+    HIPCHECK(hipMemsetAsync(h->failflag, 0, 2 * sizeof(int), h->stream));
     h->K = K;
     return INSIDER_OK;
 }
@@ -514,8 +534,20 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.sse_test = h->sse_test;
         a.test_from_stats = masked && h->no_na;
         a.fail = h->failflag;
+        a.mark = h->sweeps;          // free in the alpha == 0 path: cleared below
+        a.retry = h->failflag + 1;
+        a.only_marked = 0;
         if (h->K <= 32 && h->cd_variant == 0) {
+            if (solve) {
+                HIPCHECK(hipMemsetAsync(h->sweeps, 0, (size_t)h->p * sizeof(int), h->stream));
+                HIPCHECK(hipMemsetAsync(h->failflag + 1, 0, sizeof(int), h->stream));
+            }
             REG_DISPATCH(h->K, hipLaunchKernelGGL((k_ridge_cols_reg<SL_, KM_>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a));
+            KCHECK();
+            if (solve) {   // genes whose system was not positive definite: solve(..., likely_sympd)'s general route
+                a.only_marked = 1;
+                hipLaunchKernelGGL((k_ridge_cols<1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);   // unmarked genes exit at once
+            }
         } else {
             hipLaunchKernelGGL((k_ridge_cols<1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
         }
@@ -658,7 +690,18 @@ int launch_row_stats(insider_hip_handle *h, bool timed)
 
 int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
 {
-    if ((h->world <= 1 && !h->force_allreduce) || !h->allreduce) return INSIDER_OK;
+    if (h->world <= 1 && !h->force_allreduce) return INSIDER_OK;
+    if (h->comm) {
+        // in-library RCCL: the collective is enqueued on the library's own stream, between the kernels that produce
+        // and consume `buf`; no host synchronisation, no callback into the host language
+        const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) return fail(INSIDER_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+        return INSIDER_OK;
+    }
+    if (!h->allreduce) {
+        if (h->world > 1) return fail(INSIDER_ERR_COMM, "world > 1 needs insider_hip_comm_init() or an all-reduce callback");
+        return INSIDER_OK;
+    }
     // stream-ordered: the callback enqueues the collective against h->stream (see include/insider_hip.h)
     if (h->allreduce(h->allreduce_user, buf, count, (void *)h->stream) != 0)
         return fail(INSIDER_ERR_COMM, "all-reduce callback failed");
@@ -934,7 +977,7 @@ int check_factor_args(insider_hip_handle *h, double *const *A, const double *C, 
 // =================================================================================================================
 extern "C" {
 
-const char *insider_hip_version(void) { return "insider_hip 0.1.0 (gfx950)"; }
+const char *insider_hip_version(void) { return "insider_hip 0.2.0 (gfx950)"; }
 
 const char *insider_hip_last_error(void) { return g_err.c_str(); }
 
@@ -950,6 +993,7 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
     clear_events(h);
     free_workspace(h);
     void *ptrs[] = {h->X, h->Xt, h->codes, h->codes_t, h->lev, h->lvl_off_d, h->members_all, h->lvl_ptr_all,
@@ -1356,12 +1400,36 @@ int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, 
                           void *user)
 {
     if (!h || world < 1 || rank < 0 || rank >= world || gene_offset < 0) return fail(INSIDER_ERR_ARG, "bad shard");
-    if (world > 1 && !fn) return fail(INSIDER_ERR_ARG, "world > 1 needs an all-reduce callback");
+    // world > 1 without a callback is completed by insider_hip_comm_init(); optimize() refuses to run with neither
     h->gene_offset = gene_offset;
     h->rank = rank;
     h->world = world;
     h->allreduce = fn;
     h->allreduce_user = user;
+    return INSIDER_OK;
+}
+
+int insider_hip_comm_unique_id(void *out, int out_bytes)
+{
+    if (!out || out_bytes < (int)sizeof(ncclUniqueId)) return fail(INSIDER_ERR_ARG, "unique-id buffer too small (INSIDER_COMM_ID_BYTES)");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(INSIDER_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memset(out, 0, (size_t)out_bytes);
+    std::memcpy(out, &id, sizeof(id));
+    return INSIDER_OK;
+}
+
+int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank, int world)
+{
+    if (!h || !unique_id || world < 1 || rank < 0 || rank >= world) return fail(INSIDER_ERR_ARG, "bad communicator arguments");
+    if (h->world != world || h->rank != rank) return fail(INSIDER_ERR_ARG, "rank / world differ from insider_hip_set_shard()");
+    HIPCHECK(hipSetDevice(h->device));
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; return fail(INSIDER_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
     return INSIDER_OK;
 }
 
@@ -1382,7 +1450,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     return INSIDER_OK;
 }
 
-int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K, double lambda1,
+static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K, double lambda1,
                          double lambda2, double alpha, int tuning, double global_tol, double sub_tol, uint32_t max_iter,
                          uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss, double *traj,
                          int traj_cap, int *out_traj_rows, int *out_iters)
@@ -1390,6 +1458,9 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     int rc = check_factor_args(h, A, C, inc_continuous, tuning);
     if (rc) return rc;
     HIPCHECK(hipSetDevice(h->device));
+    // work a failed earlier call may have left on the side streams must not race with this call's
+    HIPCHECK(hipStreamSynchronize(h->side));
+    HIPCHECK(hipStreamSynchronize(h->side2));
     if ((rc = ensure_workspace(h, K))) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     clear_events(h);
@@ -1524,14 +1595,43 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
     return INSIDER_OK;
 }
 
-int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *const *A, double *C,
-                                 const int32_t *levels, int c, const int32_t *n_levels, const uint8_t *M_train,
-                                 const uint8_t *M_test, int inc_continuous, int K, double lambda1, double lambda2,
-                                 double alpha, int tuning, double global_tol, double sub_tol, uint32_t max_iter,
-                                 uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss)
+int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int inc_continuous, int K, double lambda1,
+                         double lambda2, double alpha, int tuning, double global_tol, double sub_tol, uint32_t max_iter,
+                         uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss, double *traj,
+                         int traj_cap, int *out_traj_rows, int *out_iters)
 {
+    const int rc = optimize_body(h, A, C, inc_continuous, K, lambda1, lambda2, alpha, tuning, global_tol, sub_tol, max_iter,
+                                 seed, out_train_rmse, out_test_rmse, out_loss, traj, traj_cap, out_traj_rows, out_iters);
+    if (rc != INSIDER_OK && h && h->stream) {
+        // an early return leaves enqueued work on all three streams: drain them so that the next call starts clean
+        const std::string keep = g_err;
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->side);
+        (void)hipStreamSynchronize(h->side2);
+        h->side_pending = h->qfull_pending = h->w_ready = false;
+        if (h->failflag) (void)hipMemset(h->failflag, 0, 2 * sizeof(int));
+        clear_events(h);
+        g_err = keep;
+    }
+    return rc;
+}
+
+int insider_hip_optimize_oneshot_ex(const double *X, int64_t n, int64_t p, double *const *A, double *C,
+                                    const int32_t *levels, int c, const int32_t *n_levels, const double *ctns, int m,
+                                    const uint8_t *M_train, const uint8_t *M_test, int inc_continuous, int K,
+                                    double lambda1, double lambda2, double alpha, int tuning, double global_tol,
+                                    double sub_tol, uint32_t max_iter, uint64_t seed, int device, double *out_train_rmse,
+                                    double *out_test_rmse, double *out_loss)
+{
+    if (inc_continuous != 0 && inc_continuous != 1)   // src/optimize.cpp:270-272
+        return fail(INSIDER_ERR_ARG, "The value of prarameter inc_continuous can only be 0 or 1.");
+    if (inc_continuous == 1 && (!ctns || m < 1))
+        return fail(INSIDER_ERR_ARG, "inc_continuous = 1 needs ctns_confounder (n x m, m >= 1)");
     insider_hip_handle *h = nullptr;
-    int rc = insider_hip_create(X, n, p, levels, c, n_levels, M_train, M_test, 0, &h);
+    // the reference ignores ctns_confounder when inc_continuous = 0 (src/optimize.cpp:276-291): so does the upload
+    int rc = insider_hip_create_ex(X, n, p, levels, c, n_levels, inc_continuous ? ctns : nullptr, inc_continuous ? m : 0,
+                                   M_train, M_test, device, &h);
     if (rc) return rc;
     rc = insider_hip_optimize(h, A, C, inc_continuous, K, lambda1, lambda2, alpha, tuning, global_tol, sub_tol, max_iter,
                               seed, out_train_rmse, out_test_rmse, out_loss, nullptr, 0, nullptr, nullptr);
@@ -1539,6 +1639,19 @@ int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *
     insider_hip_destroy(h);
     g_err = keep;
     return rc;
+}
+
+int insider_hip_optimize_oneshot(const double *X, int64_t n, int64_t p, double *const *A, double *C,
+                                 const int32_t *levels, int c, const int32_t *n_levels, const uint8_t *M_train,
+                                 const uint8_t *M_test, int inc_continuous, int K, double lambda1, double lambda2,
+                                 double alpha, int tuning, double global_tol, double sub_tol, uint32_t max_iter,
+                                 uint64_t seed, double *out_train_rmse, double *out_test_rmse, double *out_loss)
+{
+    if (inc_continuous == 1)
+        return fail(INSIDER_ERR_ARG, "continuous covariates need insider_hip_optimize_oneshot_ex (ctns_confounder)");
+    return insider_hip_optimize_oneshot_ex(X, n, p, A, C, levels, c, n_levels, nullptr, 0, M_train, M_test, inc_continuous,
+                                           K, lambda1, lambda2, alpha, tuning, global_tol, sub_tol, max_iter, seed, 0,
+                                           out_train_rmse, out_test_rmse, out_loss);
 }
 
 // One row update of one covariate, the reference's optimize_row() as optimize() calls it (src/optimize.cpp:339 with
@@ -1552,7 +1665,7 @@ int insider_hip_optimize_row(insider_hip_handle *h, double *const *A, const doub
     int rc = check_factor_args(h, A, C, inc_continuous, tuning);
     if (rc) return rc;
     if (cov < 0 || cov >= h->c + (inc_continuous ? h->m : 0)) return fail(INSIDER_ERR_ARG, "covariate index out of range");
-    if (lambda < 0) return fail(INSIDER_ERR_ARG, "lambda must be >= 0");
+    if (!(lambda == lambda)) return fail(INSIDER_ERR_ARG, "lambda is NaN");   // any finite value, like the reference
     HIPCHECK(hipSetDevice(h->device));
     if ((rc = ensure_workspace(h, K))) return rc;
     h->w_ready = false;
@@ -1588,30 +1701,18 @@ int insider_hip_optimize_col(insider_hip_handle *h, double *const *A, double *C,
     return check_fail_flag(h);
 }
 
-int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob, double lambda,
-                          double alpha, double tol, uint64_t seed, uint32_t iter, int order_mode,
-                          int max_sweeps, int device, double *beta_out, int32_t *sweeps_out)
+// device part shared by the two strong_coordinate_descent entries: dG / dq / dw hold nprob problems on `device`
+static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, const double *dw, int K, int64_t nprob,
+                            double lambda, double alpha, double tol, uint64_t seed, uint32_t iter, int order_mode,
+                            int max_sweeps, double *beta_out, int32_t *sweeps_out)
 {
-    if (!XtX || !Xty || !wstart || !beta_out) return fail(INSIDER_ERR_ARG, "null argument");
-    if (K < 1 || K > 64 || nprob < 0) return fail(INSIDER_ERR_ARG, "K must be in 1..64");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(INSIDER_ERR_NO_DEVICE, "no HIP device visible: libinsider_hip has no CPU fallback");
-    if (nprob == 0) return INSIDER_OK;
-    HIPCHECK(hipSetDevice(device));
-    double *dG = nullptr, *dq = nullptr, *dw = nullptr, *db = nullptr;
+    double *db = nullptr;
     int *ds = nullptr;
     int rc;
-    if ((rc = dmalloc(&dG, (size_t)nprob * K * K)) || (rc = dmalloc(&dq, (size_t)nprob * K)) ||
-        (rc = dmalloc(&dw, (size_t)nprob * K)) || (rc = dmalloc(&db, (size_t)nprob * K)) ||
-        (rc = dmalloc(&ds, (size_t)nprob)))
-        return rc;
-    HIPCHECK(hipMemcpy(dG, XtX, (size_t)nprob * K * K * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(dq, Xty, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(dw, wstart, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = bufs.alloc(&db, (size_t)nprob * K)) || (rc = bufs.alloc(&ds, (size_t)nprob))) return rc;
     const int ms = max_sweeps < 1 ? 1 : max_sweeps;
     uint8_t *dord = nullptr;
-    if ((rc = dmalloc(&dord, (size_t)(ms + 1) * ORDER_ROW))) return rc;   // + one row: the CD kernel prefetches ahead
+    if ((rc = bufs.alloc(&dord, (size_t)(ms + 1) * ORDER_ROW))) return rc;   // + one row: the CD kernel prefetches ahead
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)ms * 64, 256)), dim3(256), 0, 0, seed, iter, K, ms, order_mode, K * 8,
                        reg_kmax(K), dord);
     KCHECK();
@@ -1625,37 +1726,121 @@ int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *ws
     cd.order = dord;
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
+    bufs.events.push_back(e0);
     HIPCHECK(hipEventCreate(&e1));
+    bufs.events.push_back(e1);
     HIPCHECK(hipEventRecord(e0, 0));
     // debugging knob: INSIDER_CD_VARIANT=2 runs the LDS-resident row16 solver instead of the register-resident one
     const char *var = std::getenv("INSIDER_CD_VARIANT");
     const bool lds_variant = var && std::atoi(var) == 2;
     const size_t r16_bytes = (size_t)r16_lds_doubles(K) * sizeof(double);
     if (K <= 16 && lds_variant)
-        hipLaunchKernelGGL((k_cd_batch_r16<1>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, (const double *)dG,
-                           (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+        hipLaunchKernelGGL((k_cd_batch_r16<1>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32 && lds_variant)
-        hipLaunchKernelGGL((k_cd_batch_r16<2>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, (const double *)dG,
-                           (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+        hipLaunchKernelGGL((k_cd_batch_r16<2>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32) {
-        REG_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0,
-                                           (const double *)dG, (const double *)dq, (const double *)dw, K, nprob, cd, db,
-                                           ds));
-    } else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, (const double *)dG,
-                            (const double *)dq, (const double *)dw, K, nprob, cd, db, ds);
+        REG_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0, dG, dq, dw, K,
+                                           nprob, cd, db, ds));
+    } else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     KCHECK();
     HIPCHECK(hipEventRecord(e1, 0));
     HIPCHECK(hipDeviceSynchronize());
-    {
-        float msf = 0;
-        (void)hipEventElapsedTime(&msf, e0, e1);
-        g_last_cd_ms = msf;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-    }
+    float msf = 0;
+    (void)hipEventElapsedTime(&msf, e0, e1);
+    g_last_cd_ms = msf;
     HIPCHECK(hipMemcpy(beta_out, db, (size_t)nprob * K * sizeof(double), hipMemcpyDeviceToHost));
     if (sweeps_out) HIPCHECK(hipMemcpy(sweeps_out, ds, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(dG); (void)hipFree(dq); (void)hipFree(dw); (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dord);
+    return INSIDER_OK;
+}
+
+static int cd_common_checks(int K, int64_t nprob, int device)
+{
+    if (K < 1 || K > 64 || nprob < 0) return fail(INSIDER_ERR_ARG, "K must be in 1..64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(INSIDER_ERR_NO_DEVICE, "no HIP device visible: libinsider_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(INSIDER_ERR_ARG, "bad device ordinal");
+    return INSIDER_OK;
+}
+
+int insider_hip_strong_cd(const double *XtX, const double *Xty, const double *wstart, int K, int64_t nprob, double lambda,
+                          double alpha, double tol, uint64_t seed, uint32_t iter, int order_mode,
+                          int max_sweeps, int device, double *beta_out, int32_t *sweeps_out)
+{
+    if (!XtX || !Xty || !wstart || !beta_out) return fail(INSIDER_ERR_ARG, "null argument");
+    int rc = cd_common_checks(K, nprob, device);
+    if (rc) return rc;
+    if (nprob == 0) return INSIDER_OK;
+    HIPCHECK(hipSetDevice(device));
+    DevBufs bufs;
+    double *dG = nullptr, *dq = nullptr, *dw = nullptr;
+    if ((rc = bufs.alloc(&dG, (size_t)nprob * K * K)) || (rc = bufs.alloc(&dq, (size_t)nprob * K)) ||
+        (rc = bufs.alloc(&dw, (size_t)nprob * K)))
+        return rc;
+    HIPCHECK(hipMemcpy(dG, XtX, (size_t)nprob * K * K * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dq, Xty, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dw, wstart, (size_t)nprob * K * sizeof(double), hipMemcpyHostToDevice));
+    return strong_cd_device(bufs, dG, dq, dw, K, nprob, lambda, alpha, tol, seed, iter, order_mode, max_sweeps, beta_out,
+                            sweeps_out);
+}
+
+int insider_hip_strong_cd_xy(const double *X, const double *y, int64_t m, int K, const double *wstart, double lambda,
+                             double alpha, const double *XtX, const double *Xty, double tol, uint64_t seed, uint32_t iter,
+                             int order_mode, int max_sweeps, int device, double *beta_out, int32_t *sweeps_out)
+{
+    if (!wstart || !beta_out) return fail(INSIDER_ERR_ARG, "null argument");
+    if ((!XtX || !Xty) && (!X || !y)) return fail(INSIDER_ERR_ARG, "pass (X, y), or XtX and Xty, or all four");
+    if (m < 0) return fail(INSIDER_ERR_ARG, "m must be >= 0");
+    int rc = cd_common_checks(K, 1, device);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(device));
+    DevBufs bufs;
+    double *dG = nullptr, *dq = nullptr, *dw = nullptr;
+    if ((rc = bufs.alloc(&dG, (size_t)K * K)) || (rc = bufs.alloc(&dq, (size_t)K)) || (rc = bufs.alloc(&dw, (size_t)K)))
+        return rc;
+    if (!XtX || !Xty) {   // X'X and X'y on the device from the design matrix and outcome (src/optimize.cpp:219-222,234-235)
+        double *dX = nullptr, *dy = nullptr;
+        if ((rc = bufs.alloc(&dX, (size_t)m * K)) || (rc = bufs.alloc(&dy, (size_t)m))) return rc;
+        HIPCHECK(hipMemcpy(dX, X, (size_t)m * K * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(dy, y, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_xtx_xty, dim3(K, K + 1), dim3(64), 0, 0, (const double *)dX, (const double *)dy, m, K, dG, dq);
+        KCHECK();
+    }
+    if (XtX) HIPCHECK(hipMemcpy(dG, XtX, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice));
+    if (Xty) HIPCHECK(hipMemcpy(dq, Xty, (size_t)K * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dw, wstart, (size_t)K * sizeof(double), hipMemcpyHostToDevice));
+    return strong_cd_device(bufs, dG, dq, dw, K, 1, lambda, alpha, tol, seed, iter, order_mode, max_sweeps, beta_out,
+                            sweeps_out);
+}
+
+int insider_hip_solve_sympd(const double *A, const double *b, int K, int64_t nsys, int device, double *x, int32_t *route)
+{
+    if (!A || !b || !x) return fail(INSIDER_ERR_ARG, "null argument");
+    int rc = cd_common_checks(K, nsys, device);
+    if (rc) return rc;
+    if (nsys == 0) return INSIDER_OK;
+    HIPCHECK(hipSetDevice(device));
+    DevBufs bufs;
+    double *dA = nullptr, *db = nullptr, *dx = nullptr;
+    int *dr = nullptr;
+    if ((rc = bufs.alloc(&dA, (size_t)nsys * K * K)) || (rc = bufs.alloc(&db, (size_t)nsys * K)) ||
+        (rc = bufs.alloc(&dx, (size_t)nsys * K)) || (rc = bufs.alloc(&dr, (size_t)nsys)))
+        return rc;
+    HIPCHECK(hipMemcpy(dA, A, (size_t)nsys * K * K * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(db, b, (size_t)nsys * K * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_solve_batch, dim3((unsigned)nsys), dim3(64), 0, 0, (const double *)dA, (const double *)db, K, nsys, dx,
+                       dr);
+    KCHECK();
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(x, dx, (size_t)nsys * K * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<int> hr(nsys);
+    HIPCHECK(hipMemcpy(hr.data(), dr, (size_t)nsys * sizeof(int), hipMemcpyDeviceToHost));
+    bool singular = false;
+    for (int64_t i = 0; i < nsys; ++i) {
+        if (route) route[i] = hr[i];
+        singular = singular || hr[i] < 0;
+    }
+    if (singular) return fail(INSIDER_ERR_SOLVE, "a system is singular to working precision");
     return INSIDER_OK;
 }
 
@@ -1679,8 +1864,9 @@ static int masked_gram_common(insider_hip_handle *h, bool cols, const double *Fh
     double *stat = nullptr, *qf = nullptr, *Gd = nullptr, *qd = nullptr;
     const int NBLK = h->NB * (h->NB + 1) / 2, STAT = NBLK * 256;
     const int nseg = cols ? 1 : h->nseg;
-    if ((rc = dmalloc(&stat, (size_t)nseg * units * STAT)) || (rc = dmalloc(&qf, (size_t)units * KP)) ||
-        (rc = dmalloc(&Gd, (size_t)units * K * K)) || (rc = dmalloc(&qd, (size_t)units * K)))
+    DevBufs bufs;
+    if ((rc = bufs.alloc(&stat, (size_t)nseg * units * STAT)) || (rc = bufs.alloc(&qf, (size_t)units * KP)) ||
+        (rc = bufs.alloc(&Gd, (size_t)units * K * K)) || (rc = bufs.alloc(&qd, (size_t)units * K)))
         return rc;
     if ((rc = launch_list_stats(h, cols, nseg, F, stat))) return rc;
     // dense X'F over all entries from the gene-major copy (rows: strided reads; stand-alone API only)
@@ -1698,7 +1884,6 @@ static int masked_gram_common(insider_hip_handle *h, bool cols, const double *Fh
     HIPCHECK(hipStreamSynchronize(h->stream));
     HIPCHECK(hipMemcpy(G_out, Gd, (size_t)units * K * K * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(q_out, qd, (size_t)units * K * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(stat); (void)hipFree(qf); (void)hipFree(Gd); (void)hipFree(qd);
     // the pad rows of C (genes p..ldp-1) were not touched; R/C now hold the caller's factor
     return INSIDER_OK;
 }
@@ -1722,6 +1907,35 @@ int insider_hip_get_sweeps(insider_hip_handle *h, int32_t *out)
     HIPCHECK(hipSetDevice(h->device));
     HIPCHECK(hipStreamSynchronize(h->stream));
     HIPCHECK(hipMemcpy(out, h->sweeps, (size_t)h->p * sizeof(int), hipMemcpyDeviceToHost));
+    return INSIDER_OK;
+}
+
+int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out)
+{
+    if (!h || !name || !out) return fail(INSIDER_ERR_ARG, "null");
+    const std::string s(name);
+    const int NB = h->NB;
+    if (s == "col_stats_path") *out = col_stats_path(h);
+    else if (s == "row_merged") *out = use_merged(h, 1) ? 1.0 : 0.0;
+    else if (s == "col_entries") *out = (double)h->col_entries;      // padded held-out list entries, column side
+    else if (s == "row_entries") *out = (double)h->row_entries;
+    else if (s == "stat_doubles") *out = NB ? NB * (NB + 1) / 2 * 256.0 : 0.0;
+    else if (s == "kp") *out = h->KP;
+    else if (s == "pair_count_bytes_per_gene") *out = h->cf_pair_ok ? h->cf.cnt_stride : 0.0;
+    else if (s == "lists_bytes") *out = 12.0 * ((double)h->col_entries + (double)h->row_entries);
+    else if (s == "col_mfma_per_gene") {
+        // v_mfma_f64_16x16x4_f64 instructions the column-side statistics kernel issues per gene (2048 flops each)
+        if (!NB) return fail(INSIDER_ERR_ARG, "no workspace yet: run an update first");
+        const int path = col_stats_path(h);
+        double v = 0.0;
+        if (path == 0) v = (double)h->col_entries / (double)std::max<int64_t>(h->p, 1) / 4.0 * (NB * (NB + 1) / 2);
+        else
+            for (int t = 0; t < h->cf.c; ++t) {
+                v += std::ceil(h->cf.L[t] / 4.0) * NB * NB;                                           // M += A' P
+                if (path == 2 && h->cf.nlater[t] > 0) v += std::ceil(h->cf.L[t] / 16.0) * h->cf.nsteps * NB;   // P = N_j Tab
+            }
+        *out = v;
+    } else return fail(INSIDER_ERR_ARG, "unknown info key " + s);
     return INSIDER_OK;
 }
 

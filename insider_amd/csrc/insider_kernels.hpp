@@ -431,6 +431,46 @@ __device__ __forceinline__ bool chol_solve_lds(double *A, int KP, int K, double 
 }
 
 // ---------------------------------------------------------------------------------------------
+// General fallback of solve(XtX, Xty, likely_sympd) (src/optimize.cpp:175,190,226,240; src/fit_interaction.cpp:54):
+// Armadillo tries the Cholesky route first and, when the matrix is not positive definite, solves the general system by
+// LU with partial pivoting.  Here: Gauss-Jordan elimination with partial (row) pivoting on an LDS matrix, one wave,
+// lane r owns row r and b_r.  A: K x K used part of a row-major matrix of pitch KP, destroyed.  b: lane l < K holds
+// b_l in, x_l out.  Returns false when a pivot column is exactly zero (singular to working precision).
+// Reached only when the positive-definite route reports a non-positive pivot: the lambda = 0 updates on a
+// semidefinite level system, never on the lambda > 0 path of the BASELINE configurations.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lu_solve_lds(double *A, int KP, int K, double &b, int lane)
+{
+    const bool valid = lane < K;
+    bool used = !valid;     // rows beyond K never pivot
+    int mycol = -1;         // the column this lane's row became the pivot row of
+    for (int j = 0; j < K; ++j) {
+        double best = used ? -1.0 : fabs(A[lane * KP + j]);
+        int bi = lane;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {           // arg max |a_rj| over the unused rows, lowest row on ties
+            const double ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (!(best > 0.0)) return false;              // wave-uniform
+        const int pr = bi;
+        const double f = (lane == pr || !valid) ? 0.0 : A[lane * KP + j] / A[pr * KP + j];
+        // the pivot row has zeros in the earlier pivot columns, and it is not written in this step (f = 0 for its lane)
+        for (int c = j + 1; c < K; ++c) A[lane * KP + c] -= f * A[pr * KP + c];
+        b -= f * __shfl(b, pr, 64);
+        if (lane == pr) { used = true; mycol = j; }
+        wave_sync();
+    }
+    const double xv = mycol >= 0 ? b / A[lane * KP + mycol] : 0.0;
+    wave_sync();
+    if (mycol >= 0) A[mycol] = xv;                    // the matrix is dead: its first K entries carry x to lane order
+    wave_sync();
+    b = valid ? A[lane] : 0.0;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // wave-level solve of a symmetric positive definite system in REGISTERS (K <= KP <= 32): lane l holds row l of A
 // and b_l; Gauss-Jordan elimination without pivoting (on an SPD matrix the pivots are the d_j of L D L', all > 0,
 // and the elimination is as stable as Cholesky).  The pivot row reaches the other lanes through v_readlane into
@@ -695,6 +735,10 @@ struct RidgeArgs {
     double *sse_test;
     int test_from_stats;
     int *fail;
+    // the register-resident kernel (insider_ridge_reg.hpp) has no general route: a gene whose system is not positive
+    // definite is marked (mark[j] = 1, *retry = 1) and k_ridge_cols runs again for the marked genes only
+    int *mark, *retry;
+    int only_marked;
 };
 
 template <int WPB>
@@ -704,6 +748,7 @@ __global__ void __launch_bounds__(WPB * 64) k_ridge_cols(RidgeArgs a)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * WPB + w;
     if (j >= a.p) return;
+    if (a.only_marked && !(*a.retry && a.mark[j])) return;
     const int K = a.K, KP = a.KP;
     const bool valid = lane < K;
     double *A = s_A[w];
@@ -723,7 +768,15 @@ __global__ void __launch_bounds__(WPB * 64) k_ridge_cols(RidgeArgs a)
         if (valid) A[lane * K + lane] += a.lambda;
         wave_sync();
         double b = q;
-        const bool ok = chol_solve_lds(A, K, K, b, lane);
+        bool ok = chol_solve_lds(A, K, K, b, lane);                                     // :226,240 likely_sympd
+        if (!ok) {                                                                      // general route (lu_solve_lds)
+            wave_sync();
+            load();
+            if (valid) A[lane * K + lane] += a.lambda;
+            wave_sync();
+            b = q;
+            ok = lu_solve_lds(A, K, K, b, lane);
+        }
         if (!ok) { if (lane == 0) *a.fail = 1; }
         else beta = b;
         if (valid) a.C[(size_t)j * KP + lane] = beta;
@@ -1093,16 +1146,21 @@ __global__ void __launch_bounds__(64) k_cont_cd(const double *__restrict__ eq, i
 }
 
 // Stage 3 (one wave per level, after the cross-rank sum): add the ridge term and solve; write A_i[l].
+// solve(..., likely_sympd): the positive-definite route first (register Gauss-Jordan / LDS Cholesky); on a non-positive
+// pivot the general route (lu_solve_lds) on a fresh copy of the system; `fail` only when that is singular too.
 template <int NB>
 __global__ void __launch_bounds__(64) k_level_solve(const double *__restrict__ eq, const int *__restrict__ lvl_count,
                                                     int L, int K, double lambda, double *__restrict__ Arows /*L x KP*/,
                                                     int *__restrict__ fail)
 {
     constexpr int KP = Geo<NB>::KP;
+    __shared__ double s_A[KP * KP];
     const int l = blockIdx.x, lane = threadIdx.x;
     if (l >= L) return;
     if (lvl_count[l] == 0) return;   // level without samples: the reference never visits it (:147)
     const double *src = eq + (size_t)l * (KP * KP + KP);
+    bool ok;
+    double b = lane < KP ? src[KP * KP + lane] : 0.0;
     if constexpr (NB <= 2) {
         // row `lane` of XtX in registers (the matrix is symmetric: column walks are coalesced)
         double row[KP];
@@ -1110,21 +1168,69 @@ __global__ void __launch_bounds__(64) k_level_solve(const double *__restrict__ e
         for (int c = 0; c < KP; ++c) row[c] = lane < KP ? src[c * KP + lane] : 0.0;
 #pragma unroll
         for (int c = 0; c < KP; ++c) row[c] += (c == lane && lane < K) ? lambda : 0.0;      // :174,187
-        double b = lane < KP ? src[KP * KP + lane] : 0.0;
-        const bool ok = gj_solve_regs<KP>(row, K, b, lane);                                 // :175,190
-        if (!ok) { if (lane == 0) *fail = 1; return; }
-        if (lane < K) Arows[(size_t)l * KP + lane] = b;
+        ok = gj_solve_regs<KP>(row, K, b, lane);                                            // :175,190
     } else {
-        __shared__ double s_A[KP * KP];
         for (int i = lane; i < KP * KP; i += WAVE) s_A[i] = src[i];
         wave_sync();
         if (lane < K) s_A[lane * KP + lane] += lambda;                                      // :174,187
-        double b = lane < KP ? src[KP * KP + lane] : 0.0;
         wave_sync();
-        const bool ok = chol_solve_lds(s_A, KP, K, b, lane);                                // :175,190
-        if (!ok) { if (lane == 0) *fail = 1; return; }
-        if (lane < K) Arows[(size_t)l * KP + lane] = b;
+        ok = chol_solve_lds(s_A, KP, K, b, lane);                                           // :175,190
     }
+    if (!ok) {                                                                              // general route
+        wave_sync();
+        for (int i = lane; i < KP * KP; i += WAVE) s_A[i] = src[i];
+        wave_sync();
+        if (lane < K) s_A[lane * KP + lane] += lambda;
+        b = lane < KP ? src[KP * KP + lane] : 0.0;
+        wave_sync();
+        if (!lu_solve_lds(s_A, KP, K, b, lane)) { if (lane == 0) *fail = 1; return; }
+    }
+    if (lane < K) Arows[(size_t)l * KP + lane] = b;
+}
+
+// X'X (K x K, column-major) and X'y of an m x K column-major design matrix and outcome: what the reference's callers
+// hand to strong_coordinate_descent next to (X, y) (src/optimize.cpp:219-222,228; :234-235,246).  One wave per output
+// entry (a, b), b == K selects y; fixed-order reduction.
+__global__ void __launch_bounds__(64) k_xtx_xty(const double *__restrict__ X, const double *__restrict__ y, int64_t m, int K,
+                                                double *__restrict__ XtX, double *__restrict__ Xty)
+{
+    const int a = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const double *xa = X + (size_t)a * m, *xb = b < K ? X + (size_t)b * m : y;
+    double acc = 0.0;
+    for (int64_t i = lane; i < m; i += WAVE) acc = fma(xa[i], xb[i], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (b < K) XtX[a + (size_t)b * K] = acc;
+        else Xty[a] = acc;
+    }
+}
+
+// solve(A, b, likely_sympd) on its own, batched: one wave per K x K system (column-major = row-major of A', and the
+// positive-definite route needs A symmetric; the general route solves A' x = b for the transposed read, so the matrix
+// is loaded transposed to keep A x = b for non-symmetric input).  route[s]: 0 = Cholesky, 1 = general, -1 = singular.
+__global__ void __launch_bounds__(64) k_solve_batch(const double *__restrict__ A, const double *__restrict__ bvec, int K,
+                                                    int64_t nsys, double *__restrict__ x, int *__restrict__ route)
+{
+    __shared__ double s_A[64 * 64];
+    const int64_t sidx = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (sidx >= nsys) return;
+    const double *src = A + (size_t)sidx * K * K;
+    auto load = [&]() {
+        for (int i = lane; i < K * K; i += WAVE) s_A[(i % K) * K + (i / K)] = src[i];   // element (r, c) at r * K + c
+        wave_sync();
+    };
+    load();
+    double b = lane < K ? bvec[(size_t)sidx * K + lane] : 0.0;
+    int rt = 0;
+    if (!chol_solve_lds(s_A, K, K, b, lane)) {
+        wave_sync();
+        load();
+        b = lane < K ? bvec[(size_t)sidx * K + lane] : 0.0;
+        rt = lu_solve_lds(s_A, K, K, b, lane) ? 1 : -1;
+    }
+    if (lane < K) x[(size_t)sidx * K + lane] = b;
+    if (lane == 0 && route) route[sidx] = rt;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(64, 2) k_ridge_cols_reg(RidgeArgs a)   // 256 
             for (int k = 0; k < KMAX; ++k) G[u][k] += (k == 16 * u + i && gene && k < K) ? a.lambda : 0.0;   // :224,237
         }
         const bool ok = ridge_solve_regs<SLOTS, KMAX>(G, b, K, i);                       // :226,240
-        if (__any(gene && !ok)) { if (lane == 0) *a.fail = 1; }
+        // not positive definite: the general route of solve(..., likely_sympd) runs in k_ridge_cols for the marked genes
+        if (gene && !ok && i == 0) { a.mark[j] = 1; *a.retry = 1; }
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
             if (gene && ok) beta[u] = b[u];

@@ -137,15 +137,42 @@ class StagedHostAllreduce:
         self.calls.append(count)
 
 
-def attach(ds, gene_offset, rank, world, device=None, group=None, force=False, staged=False):
-    """Mark an InsiderData handle as one gene slab of a `world`-rank job and install the RCCL all-reduce.
-    ``force``: install (and call) the all-reduce even for world == 1 (plumbing rehearsal on a single GPU).
-    ``staged``: all-reduce through the host with the process group's CPU backend (several ranks on one GPU)."""
+def broadcast_comm_id(rank, group=None):
+    """The RCCL unique id of the in-library communicator: made by rank 0 (insider_hip_comm_unique_id), handed to every
+    rank over torch.distributed (any backend).  Without a process group (world 1) rank 0's own id is returned."""
+    from . import _lib
+    buf = (C.c_char * _lib.COMM_ID_BYTES)()
+    if rank == 0:
+        _lib.check(_lib.load().insider_hip_comm_unique_id(buf, _lib.COMM_ID_BYTES))
+    box = [bytes(buf)]
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+    except ImportError:
+        pass
+    return box[0]
+
+
+def attach(ds, gene_offset, rank, world, device=None, group=None, force=False, staged=False, mode=None):
+    """Mark an InsiderData handle as one gene slab of a `world`-rank job and install the cross-rank all-reduce.
+
+    ``mode``: "rccl" (default) = the library's own RCCL communicator, ncclAllReduce enqueued on the library's stream
+    (insider_hip_comm_init; the unique id travels over torch.distributed once); "torch" = callback into
+    torch.distributed on the library's stream (DeviceAllreduce); "staged" (or ``staged=True``) = through the host with
+    the process group's CPU backend (several ranks on one GPU, where RCCL refuses duplicate devices).
+    ``force``: install (and call) the all-reduce even for world == 1 (plumbing rehearsal on a single GPU)."""
     if world <= 1 and not force:
         ds.set_shard(gene_offset, 0, 1, None)
         return None
-    ar = StagedHostAllreduce(group) if staged else DeviceAllreduce(device if device is not None else 0, group)
-    ds.set_shard(gene_offset, rank, world, ar)
+    mode = "staged" if staged else (mode or "rccl")
+    if mode == "rccl":
+        ds.set_shard(gene_offset, rank, world, None)
+        ds.comm_init(broadcast_comm_id(rank, group), rank, world)
+        ar = "rccl"
+    else:
+        ar = StagedHostAllreduce(group) if mode == "staged" else DeviceAllreduce(device if device is not None else 0, group)
+        ds.set_shard(gene_offset, rank, world, ar)
     if force:
         ds.set_option("force_allreduce", 1)
     return ar

@@ -43,6 +43,34 @@ def num_procs():
     return int(lib().oracle_num_procs())
 
 
+def set_col_chunk(chunk=100):
+    """OpenMP chunk of the per-gene loops (reference: schedule(dynamic, 100), src/optimize.cpp:213,243).  A bounded gene
+    sample needs chunk 1 to occupy every thread; results do not depend on it (genes are independent)."""
+    lib().oracle_set_col_chunk(C.c_int(int(chunk)))
+
+
+def set_cd_form(form=0):
+    """0 = residual-form CD (the reference's formulation; the parity oracle), 1 = covariance-form sweeps (LABELLED
+    CPU-optimised variant for bench.py's cpu_baseline, never used as the checker)."""
+    lib().oracle_set_cd_form(C.c_int(int(form)))
+
+
+def strong_cd_cov(wstart, lam, alpha, XtX, Xty, tol=1e-5, seed=0, it=0, order_mode=0, max_sweeps=10000):
+    """Covariance-form variant of strong_cd (see set_cd_form). Returns (beta, sweeps)."""
+    XtX = _f64(XtX)
+    Xty = _f64(Xty)
+    w = _f64(wstart)
+    K = Xty.shape[0]
+    beta = np.zeros(K)
+    sw = C.c_int(0)
+    rc = lib().oracle_strong_cd_cov(C.c_int(K), _p(w), C.c_double(lam), C.c_double(alpha), _p(XtX), _p(Xty),
+                                    C.c_double(tol), C.c_uint64(seed), C.c_uint32(it), C.c_int(order_mode),
+                                    C.c_int(max_sweeps), _p(beta), C.byref(sw))
+    if rc:
+        raise RuntimeError(f"oracle_strong_cd_cov failed rc={rc}")
+    return beta, sw.value
+
+
 def solve_sympd(A, b):
     A = _f64(A)
     b = _f64(b)

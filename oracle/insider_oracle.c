@@ -51,6 +51,17 @@
 #define ORACLE_ERR_SOLVE 2
 #define ORACLE_ERR_ALLOC 3
 
+/* Bench / test knobs (defaults = the reference's behaviour).
+ * g_col_chunk: OpenMP chunk of the per-gene loops (src/optimize.cpp:213,243 use schedule(dynamic, 100)); a
+ *   bounded gene SAMPLE of a workload needs a smaller chunk to occupy all threads (bench.py cpu_baseline).
+ * g_cd_form: 0 = residual-form coordinate descent, the reference's formulation (src/coordinate_descent.cpp:86-114);
+ *   1 = covariance-form sweeps on (XtX, Xty) — a LABELLED CPU-optimised variant, same
+ *   iterates in exact arithmetic, K^2 instead of 4 K m flops per sweep.  Never the parity oracle. */
+static int g_col_chunk = 100;
+static int g_cd_form = 0;
+void oracle_set_col_chunk(int chunk) { g_col_chunk = chunk < 1 ? 1 : chunk; }
+void oracle_set_cd_form(int form) { g_cd_form = form ? 1 : 0; }
+
 static double now_s(void)
 {
 #ifdef _OPENMP
@@ -246,6 +257,83 @@ int oracle_strong_cd(const double *X, const double *y, int m, int K, const doubl
         if (nviol == 0) break;
     }
     free(resid);
+    if (sweeps_out) *sweeps_out = (int)sweep;
+    return ORACLE_OK;
+}
+
+/* Covariance-form variant of the same solver (labelled CPU-optimised baseline, g_cd_form = 1): the inner product
+ * dot(residual, X_k) of :94 is (Xty - XtX beta)_k, the residual update of :107 is a K-vector update of that
+ * gradient, and the loss of :112 is 0.5 (y'y - 2 beta'Xty + beta'XtX beta) + penalty, whose constant y'y cancels
+ * in the stopping rule of :114.  Same screening, order and KKT loop as oracle_strong_cd. */
+int oracle_strong_cd_cov(int K, const double *wstart, double lambda, double alpha, const double *XtX,
+                         const double *Xty, double tol, uint64_t seed, uint32_t iter, int order_mode,
+                         int max_sweeps, double *beta, int *sweeps_out)
+{
+    if (K < 1 || K > 64) return ORACLE_ERR_ARG;
+    int active[64], inc[64], ex[64], ord[64];
+    double g[64];
+    double mx = 0.0;
+    for (int k = 0; k < K; k++) if (fabs(Xty[k]) > mx) mx = fabs(Xty[k]);
+    double thr = alpha * (2 * lambda - mx);
+    for (int k = 0; k < K; k++) {
+        beta[k] = wstart[k];
+        active[k] = 1;
+        if (fabs(Xty[k]) < thr) { active[k] = 0; beta[k] = 0.0; }
+    }
+    for (int a = 0; a < K; a++) {
+        double s = Xty[a];
+        for (int k = 0; k < K; k++) s -= XtX[a + (size_t)k * K] * beta[k];
+        g[a] = s;
+    }
+#define COV_LOSS(out)                                                                              \
+    do {                                                                                           \
+        double q_ = 0.0, b2_ = 0.0, b1_ = 0.0;                                                     \
+        for (int k_ = 0; k_ < K; k_++) {                                                           \
+            q_ -= beta[k_] * (Xty[k_] + g[k_]);                                                    \
+            b2_ += beta[k_] * beta[k_];                                                            \
+            b1_ += fabs(beta[k_]);                                                                 \
+        }                                                                                          \
+        (out) = q_ / 2 + (1 - alpha) * lambda * b2_ / 2 + alpha * lambda * b1_;                    \
+    } while (0)
+    double iter_loss, pre_loss;
+    COV_LOSS(iter_loss);
+    uint32_t sweep = 0;
+    int capped = 0;
+    for (;;) {
+        int ninc = 0, nex = 0;
+        for (int k = 0; k < K; k++) { if (active[k]) inc[ninc++] = k; else ex[nex++] = k; }
+        do {
+            pre_loss = iter_loss;
+            sweep_order(inc, ninc, seed, iter, sweep, order_mode, ord);
+            sweep++;
+            for (int t = 0; t < ninc; t++) {
+                int k = ord[t];
+                double gkk = XtX[k + (size_t)k * K];
+                double u = g[k] + beta[k] * gkk;
+                double upd;
+                if (fabs(u) > lambda * alpha) {
+                    double sg = (u > 0) - (u < 0);
+                    upd = sg * fmax(fabs(u) - lambda * alpha, 0.0) / (gkk + lambda * (1 - alpha));
+                } else upd = 0.0;
+                if (upd != beta[k]) {
+                    double d = upd - beta[k];
+                    const double *col = XtX + (size_t)k * K;
+                    for (int a = 0; a < K; a++) g[a] -= d * col[a];
+                    beta[k] = upd;
+                }
+            }
+            COV_LOSS(iter_loss);
+            if ((int)sweep >= max_sweeps) { capped = 1; break; }
+        } while (fabs(pre_loss - iter_loss) > tol);
+        if (capped) break;
+        int nviol = 0;
+        for (int e = 0; e < nex; e++) {
+            int r = ex[e];
+            if (fabs(g[r]) > alpha * lambda) { active[r] = 1; nviol++; }   /* beta[r] = 0: g[r] = Xty - XtX[r,inc] beta */
+        }
+        if (nviol == 0) break;
+    }
+#undef COV_LOSS
     if (sweeps_out) *sweeps_out = (int)sweep;
     return ORACLE_OK;
 }
@@ -452,7 +540,10 @@ int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x
             for (int b = 0; b < K; b++)
                 for (int a = 0; a < K; a++)
                     cube[(size_t)i * K * K + a + (size_t)b * K] = R[i + (size_t)a * n] * R[i + (size_t)b * n];
-#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 100) reduction(+ : sweeps_sum)
+#ifdef _OPENMP
+        omp_set_schedule(omp_sched_dynamic, g_col_chunk);                   /* :213 schedule(dynamic, 100) */
+#endif
+#pragma omp parallel for num_threads(n_threads) schedule(runtime) reduction(+ : sweeps_sum)
         for (int j = 0; j < p; j++) {
             const double *xcol = X + (size_t)j * n;
             const uint8_t *mcol = M + (size_t)j * n;
@@ -492,8 +583,11 @@ int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x
                     for (int a = 0; a < K; a++) cj[a] = Xty[a];
             } else {                                                                /* :228 */
                 int sw = 0;
-                oracle_strong_cd(feat, outc, m, K, cj, lambda, alpha, XtX, Xty, tol, seed,
-                                 (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
+                if (g_cd_form == 1)
+                    oracle_strong_cd_cov(K, cj, lambda, alpha, XtX, Xty, tol, seed, iter, order_mode, max_sweeps, beta, &sw);
+                else
+                    oracle_strong_cd(feat, outc, m, K, cj, lambda, alpha, XtX, Xty, tol, seed,
+                                     (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
                 sweeps_sum += sw;
                 for (int a = 0; a < K; a++) cj[a] = beta[a];
             }
@@ -505,7 +599,10 @@ int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x
         if (alpha == 0.0) {
             for (int a = 0; a < K; a++) gram[a + (size_t)a * K] += lambda;
         }
-#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 100) reduction(+ : sweeps_sum)
+#ifdef _OPENMP
+        omp_set_schedule(omp_sched_dynamic, g_col_chunk);                   /* :243 schedule(dynamic, 100) */
+#endif
+#pragma omp parallel for num_threads(n_threads) schedule(runtime) reduction(+ : sweeps_sum)
         for (int j = 0; j < p; j++) {
             const double *xcol = X + (size_t)j * n;
             double *Xty = (double *)malloc(sizeof(double) * (size_t)K);
@@ -529,8 +626,11 @@ int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x
                     for (int a = 0; a < K; a++) cj[a] = Xty[a];
             } else {                                                                /* :246 */
                 int sw = 0;
-                oracle_strong_cd(R, xcol, n, K, cj, lambda, alpha, gram, Xty, tol, seed,
-                                 (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
+                if (g_cd_form == 1)
+                    oracle_strong_cd_cov(K, cj, lambda, alpha, gram, Xty, tol, seed, iter, order_mode, max_sweeps, beta, &sw);
+                else
+                    oracle_strong_cd(R, xcol, n, K, cj, lambda, alpha, gram, Xty, tol, seed,
+                                     (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
                 sweeps_sum += sw;
                 for (int a = 0; a < K; a++) cj[a] = beta[a];
             }

@@ -1,0 +1,68 @@
+# insider_hip.R — R side of the MI355X path for kai0511/insider: source() it after library(insider), or copy it into
+# the package's R/ directory in place of the two wrappers it re-points (R/RcppExports.R:8-10,20-22).
+# Needs r/insider_hip_shim.c built against libinsider_hip.so (see that file's header).  Not runnable in this
+# repository's pipeline (no R in the image); the same C ABI is exercised through ctypes by tests/test_gpu_boundary.py.
+
+insider_hip_load <- function(dir = Sys.getenv("INSIDER_HIP_DIR", ".")) {
+    dyn.load(file.path(dir, "libinsider_hip.so"), local = FALSE)   # the C ABI (include/insider_hip.h)
+    dyn.load(file.path(dir, "insiderhip.so"))                       # R CMD SHLIB -o insiderhip.so insider_hip_shim.c -linsider_hip
+    invisible(TRUE)
+}
+
+insider_hip_available <- function() {
+    is.loaded("insider_hip_available_R") && isTRUE(.Call("insider_hip_available_R"))
+}
+
+# optimize(): R/RcppExports.R:20-22 with the same 16 arguments (+ seed, device).  Every combination the reference
+# accepts goes to the GPU, continuous covariates included; the CPU reference is used only when no MI355X is visible.
+optimize <- function(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, train_indicator,
+                     test_indicator, inc_continuous, latent_dim, lambda1 = 1.0, lambda2 = 1.0, alpha = 0.1,
+                     tuning = 1L, global_tol = 1e-10, sub_tol = 1e-5, max_iter = 10000L,
+                     seed = sample.int(.Machine$integer.max, 1), device = 0L) {
+    if (insider_hip_available())
+        .Call("insider_hip_optimize_R", data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
+              train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
+              global_tol, sub_tol, max_iter, seed, device)
+    else
+        .Call(`_insider_optimize`, data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
+              train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
+              global_tol, sub_tol, max_iter)
+}
+
+# strong_coordinate_descent(): R/RcppExports.R:8-10.  XtX / Xty may be NULL (formed on the device from X, y).
+strong_coordinate_descent <- function(X, y, wstart, lambda, alpha, XtX = NULL, Xty = NULL, tol = 1e-5,
+                                      seed = sample.int(.Machine$integer.max, 1), device = 0L) {
+    if (insider_hip_available())
+        .Call("insider_hip_strong_cd_R", X, y, wstart, lambda, alpha, XtX, Xty, tol, seed, device)
+    else
+        .Call(`_insider_strong_coordinate_descent`, X, y, wstart, lambda, alpha, XtX, Xty, tol)
+}
+
+# ---- .RData-free exchange with `python -m insider_amd.fit` (insider_amd/flatio.py reads / writes the same layout) ----
+# A directory of raw little-endian column-major arrays plus manifest.json: X.f64 (n x p), levels.i32 (n x c, 1-based),
+# train.u8 / test.u8 (n x p), optional ctns.f64 (n x m).  Results come back as A<i>.f64 (L_i x K), C.f64 (K x p) and
+# result.json.
+insider_write_flat <- function(object, dir) {
+    dir.create(dir, showWarnings = FALSE, recursive = TRUE)
+    wr <- function(v, name, what, size) { con <- file(file.path(dir, name), "wb"); writeBin(what(v), con, size = size, endian = "little"); close(con) }
+    wr(object$data, "X.f64", as.double, 8)
+    wr(object$confounder, "levels.i32", as.integer, 4)
+    wr(object$train_indicator, "train.u8", as.integer, 1)
+    wr(object$test_indicator, "test.u8", as.integer, 1)
+    m <- 0L
+    if (object$inc_continuous == 1) { wr(object$ctns_confounder, "ctns.f64", as.double, 8); m <- ncol(object$ctns_confounder) }
+    writeLines(sprintf('{"n": %d, "p": %d, "c": %d, "m": %d, "format": "insider-flat-1"}', nrow(object$data), ncol(object$data),
+                       ncol(object$confounder), m), file.path(dir, "manifest.json"))
+    invisible(dir)
+}
+
+insider_read_flat_fit <- function(object, dir, latent_dimension) {
+    rd <- function(name, nrow, ncol) matrix(readBin(file.path(dir, name), "double", n = nrow * ncol, size = 8, endian = "little"), nrow, ncol)
+    nfac <- ncol(object$confounder) + (object$inc_continuous == 1)
+    object$cfd_matrices <- lapply(seq_len(nfac), function(i) {
+        L <- if (i <= ncol(object$confounder)) length(unique(object$confounder[, i])) else ncol(object$ctns_confounder)
+        rd(sprintf("A%d.f64", i - 1L), L, latent_dimension)
+    })
+    object$column_factor <- rd("C.f64", latent_dimension, ncol(object$data))
+    object
+}

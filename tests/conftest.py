@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "multi_gpu: needs at least two MI355X on one node (skips itself otherwise)")
 
 
 @pytest.fixture(scope="session")

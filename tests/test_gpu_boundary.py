@@ -1,0 +1,219 @@
+"""The drop-in boundary itself (include/insider_hip.h), called through ctypes the way r/insider_hip_shim.c calls it:
+the one-shot symbols that replace .Call(`_insider_optimize`) and .Call(`_insider_strong_coordinate_descent`), the
+general route of solve(..., likely_sympd), error paths that must leave a handle usable.  All against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from insider_amd import _lib, api, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if _lib.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X box")
+
+
+def _raw_oneshot(w, A, Cm, ctns=None, ex=True, max_iter=12, seed=5):
+    """insider_hip_optimize_oneshot[_ex] with raw pointers: no Python wrapper between the test and the symbol."""
+    lib = _lib.load()
+    dp = C.POINTER(C.c_double)
+    X = np.asfortranarray(w.X, dtype=np.float64)
+    lev = np.asfortranarray(w.levels, dtype=np.int32)
+    nl = np.ascontiguousarray(w.n_levels, dtype=np.int32)
+    Mtr = np.asfortranarray(w.M_train, dtype=np.uint8)
+    Mte = np.asfortranarray(w.M_test, dtype=np.uint8)
+    Aptrs = (dp * len(A))(*[a.ctypes.data_as(dp) for a in A])
+    tr, te, lo = C.c_double(), C.c_double(), C.c_double()
+    n, p = X.shape
+    common = (X.ctypes.data_as(dp), n, p, Aptrs, Cm.ctypes.data_as(dp), lev.ctypes.data_as(C.POINTER(C.c_int32)),
+              lev.shape[1], nl.ctypes.data_as(C.POINTER(C.c_int32)))
+    masks = (Mtr.ctypes.data_as(C.POINTER(C.c_uint8)), Mte.ctypes.data_as(C.POINTER(C.c_uint8)))
+    tail = (w.K, w.lam, w.lam, w.alpha, w.tuning, 1e-10, 1e-5, max_iter, seed)
+    if ex:
+        Z = np.asfortranarray(ctns, dtype=np.float64) if ctns is not None else None
+        rc = lib.insider_hip_optimize_oneshot_ex(*common, Z.ctypes.data_as(dp) if Z is not None else None,
+                                                 Z.shape[1] if Z is not None else 0, *masks,
+                                                 1 if Z is not None else 0, *tail, 0, C.byref(tr), C.byref(te), C.byref(lo))
+    else:
+        rc = lib.insider_hip_optimize_oneshot(*common, *masks, 0, *tail, C.byref(tr), C.byref(te), C.byref(lo))
+    return rc, tr.value, te.value, lo.value
+
+
+@pytest.mark.parametrize("ex", [False, True])
+@pytest.mark.parametrize("kw", [dict(), dict(tuning=0), dict(with_na=True, interaction_idx=(1, 2))])
+def test_oneshot_symbol_matches_oracle(oracle, kw, ex):
+    w = workloads.small(n=64, p=80, K=5, **kw)
+    A = [a.copy(order="F") for a in w.A0]
+    Cm = w.C0.copy(order="F")
+    rc, tr, te, lo = _raw_oneshot(w, A, Cm, ex=ex)
+    assert rc == _lib.OK, _lib.load().insider_hip_last_error()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          tuning=w.tuning, max_iter=12, seed=5)
+    assert relerr(Cm, ref["column_factor"]) < 1e-7                  # updated in place (src/optimize.cpp:283-284)
+    for a, r in zip(A, ref["row_matrices"]):
+        assert relerr(a, r) < 1e-7
+    assert lo == pytest.approx(ref["loss"], rel=1e-9) and tr == pytest.approx(ref["train_rmse"], rel=1e-9)
+    if w.tuning == 1:
+        assert te == pytest.approx(ref["test_rmse"], rel=1e-9)
+    else:
+        assert np.isnan(te)
+
+
+def test_oneshot_ex_with_continuous_covariates(oracle):
+    """inc_continuous = 1 through the one-shot symbol (the R wrapper never has to fall back to the CPU reference)."""
+    w = workloads.small(n=70, p=60, K=4, with_na=True)
+    rng = np.random.default_rng(3)
+    Z = np.asfortranarray(rng.standard_normal((w.n, 2)))
+    U0 = np.asfortranarray(rng.normal(0, 0.001, size=(2, w.K)))
+    A = [a.copy(order="F") for a in w.A0] + [U0.copy(order="F")]
+    Cm = w.C0.copy(order="F")
+    rc, tr, te, lo = _raw_oneshot(w, A, Cm, ctns=Z, max_iter=10, seed=8)
+    assert rc == _lib.OK, _lib.load().insider_hip_last_error()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + [U0], w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
+                          tuning=1, max_iter=10, seed=8, ctns=Z)
+    assert relerr(Cm, ref["column_factor"]) < 1e-7 and relerr(A[-1], ref["row_matrices"][-1]) < 1e-7
+    assert lo == pytest.approx(ref["loss"], rel=1e-9) and te == pytest.approx(ref["test_rmse"], rel=1e-9)
+    # the plain one-shot refuses continuous covariates with a status, it does not compute something else
+    lib = _lib.load()
+    assert _raw_oneshot(w, [a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), ex=False)[0] == _lib.OK
+    with pytest.raises(_lib.InsiderError) as e:
+        api.optimize(w.X, w.A0, w.C0, w.levels, None, w.M_train, w.M_test, 1, w.K)
+    assert e.value.status == _lib.ERR_ARG
+    assert b"ctns" in lib.insider_hip_last_error()
+
+
+@pytest.mark.parametrize("K,m", [(1, 2), (7, 150), (30, 9000), (40, 333)])
+def test_strong_cd_from_design_matrix_and_outcome(oracle, K, m):
+    """The eight-argument form of .Call(`_insider_strong_coordinate_descent`): (X, y) alone [X'X, X'y formed on the
+    device], (XtX, Xty) alone, and all four, against the oracle's residual-form solver on (X, y)."""
+    rng = np.random.default_rng(K)
+    X = np.asfortranarray(rng.standard_normal((m, K)))
+    y = X @ (rng.standard_normal(K) * (rng.random(K) < 0.6)) + 0.5 * rng.standard_normal(m)
+    w0 = rng.standard_normal(K) * 0.05
+    G, q = X.T @ X, X.T @ y
+    lam, alpha, tol = 4.0, 0.4, 1e-9
+    ref, ref_sw = oracle.strong_cd(X, y, w0, lam, alpha, G, q, tol=tol, seed=21, it=3)
+    for args in ((X, y, None, None), (None, None, G, q), (X, y, G, q)):
+        beta, sw = api.strong_coordinate_descent(args[0], args[1], w0, lam, alpha, args[2], args[3], tol=tol, seed=21,
+                                                 it=3, return_sweeps=True)
+        assert np.max(np.abs(beta - ref)) < 1e-8 * max(1.0, np.max(np.abs(ref)))
+        assert np.array_equal(beta == 0, ref == 0) and abs(sw - ref_sw) <= 1
+    with pytest.raises(_lib.InsiderError):
+        api.strong_coordinate_descent(None, None, w0, lam, alpha)
+
+
+def test_solve_likely_sympd_routes(oracle):
+    """solve(A, b, likely_sympd): Cholesky for positive definite systems, the general route (partial pivoting) for
+    symmetric indefinite and for non-symmetric ones, a status for singular ones — vs numpy and the oracle's restatement."""
+    rng = np.random.default_rng(0)
+    for K in (1, 3, 16, 31, 32, 47, 64):
+        B = 6
+        M = rng.standard_normal((B, K, K))
+        spd = M @ np.transpose(M, (0, 2, 1)) + 0.5 * np.eye(K)
+        sym = M + np.transpose(M, (0, 2, 1))                        # symmetric, indefinite (K > 1)
+        sym[:, 0, 0] = -np.abs(sym[:, 0, 0]) - 1.0                   # a non-positive first pivot for sure
+        gen = M + 3.0 * np.eye(K)
+        gen[:, 0, 0] = -2.0
+        b = rng.standard_normal((B, K))
+        for mats, want in ((spd, 0), (sym, 1), (gen, 1)):
+            x, route = api.solve_sympd(mats, b, return_route=True)
+            assert np.all(route == want), (K, want, route)
+            ref = np.linalg.solve(mats, b[..., None])[..., 0]
+            assert relerr(x, ref) < 1e-9 * max(1.0, np.linalg.cond(mats[0]))
+            assert relerr(x[0], oracle.solve_sympd(mats[0], b[0])) < 1e-9 * max(1.0, np.linalg.cond(mats[0]))
+    sing = np.zeros((2, 4, 4))
+    sing[0] = np.eye(4)
+    with pytest.raises(_lib.InsiderError) as e:
+        api.solve_sympd(sing, np.ones((2, 4)))
+    assert e.value.status == _lib.ERR_SOLVE
+
+
+@pytest.mark.parametrize("tuning", [1, 0])
+@pytest.mark.parametrize("K", [6, 40])
+def test_row_update_general_route_when_not_positive_definite(oracle, K, tuning):
+    """A level system that is not positive definite (here: a negative ridge term, which the reference accepts) must be
+    solved by the general route of solve(..., likely_sympd) (src/optimize.cpp:175,190; src/fit_interaction.cpp:54),
+    not refused: K = 6 takes the register solver's fallback, K = 40 the LDS solver's."""
+    w = workloads.small(n=90, p=70, K=K, level_counts=(5, 3), seed=K)
+    rng = np.random.default_rng(2)
+    A = [np.asfortranarray(rng.standard_normal(a.shape) * 0.3) for a in w.A0]
+    Cm = np.asfortranarray(rng.standard_normal(w.C0.shape) * 0.3)
+    gram = Cm @ Cm.T
+    ev = np.linalg.eigvalsh(gram * (w.n / 5))                    # scale of a level's XtX
+    lam = -0.5 * (ev[len(ev) // 2] + ev[len(ev) // 2 - 1]) if K > 1 else -1.0   # between two eigenvalues: indefinite
+    R = sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]))
+    resid = w.X - (R - A[0][w.levels[:, 0] - 1, :]) @ Cm
+    ref = oracle.optimize_row(resid, w.M_train, A[0], Cm, w.levels[:, 0], gram, lam, tuning=tuning)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize_row([a.copy(order="F") for a in A], Cm, 0, lambda_=lam, tuning=tuning)
+    ds.close()
+    assert relerr(got, ref) < 1e-7, relerr(got, ref)
+
+
+@pytest.mark.parametrize("K", [5, 20, 40])
+def test_ridge_column_update_general_route(oracle, K):
+    """alpha = 0 with XtX_j + lambda I not positive definite (src/optimize.cpp:224-226): the register-resident ridge
+    kernel marks the gene and the general route solves it (K <= 32), the LDS kernel falls back in place (K = 40)."""
+    w = workloads.small(n=80, p=50, K=K, level_counts=(6, 4), seed=3 + K)
+    rng = np.random.default_rng(5)
+    A = [np.asfortranarray(rng.standard_normal(a.shape) * 0.5) for a in w.A0]
+    Cm = np.asfortranarray(rng.standard_normal(w.C0.shape) * 0.1)
+    R = sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]))
+    ev = np.linalg.eigvalsh(R.T @ R)
+    lam = -0.5 * (ev[-1] + ev[-2]) if K > 1 else -1.0             # below the top eigenvalue only: indefinite for every gene
+    ref, _ = oracle.optimize_col(w.X, w.M_train, R, Cm, lam, 0.0, tuning=1)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    got = ds.optimize_col([a.copy(order="F") for a in A], Cm.copy(order="F"), lambda_=lam, alpha=0.0, tuning=1)
+    good = ds.optimize_col([a.copy(order="F") for a in A], Cm.copy(order="F"), lambda_=2.0, alpha=0.0, tuning=1)
+    ds.close()
+    assert relerr(got, ref) < 1e-6, relerr(got, ref)
+    ref2, _ = oracle.optimize_col(w.X, w.M_train, R, Cm, 2.0, 0.0, tuning=1)
+    assert relerr(good, ref2) < 1e-9                              # the marks of the failed call do not leak into the next
+
+
+def test_failed_optimize_leaves_the_handle_usable(oracle):
+    """A singular level system (lambda1 = 0 and a dead latent dimension: no route can solve it) makes optimize() return
+    INSIDER_ERR_SOLVE from inside the outer loop; the side streams are drained and the next call on the handle gives the
+    oracle's result."""
+    w = workloads.small(n=60, p=64, K=4)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    A, Cm = [a.copy(order="F") for a in w.A0], w.C0.copy(order="F")
+    Cm[2, :] = 0.0
+    with pytest.raises(_lib.InsiderError) as e:
+        ds.optimize(A, Cm, w.K, 0.0, w.lam, w.alpha, tuning=1, max_iter=20, seed=3)
+    assert e.value.status == _lib.ERR_SOLVE
+    with pytest.raises(RuntimeError):      # the oracle (Cholesky, then LU on an exactly zero pivot column) refuses it too
+        Cz = w.C0.copy(order="F")
+        Cz[2, :] = 0.0
+        oracle.optimize(w.X, w.levels, w.n_levels, w.A0, Cz, w.M_train, w.M_test, 0.0, w.lam, w.alpha, max_iter=20, seed=3)
+    got = ds.optimize([a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=1,
+                      max_iter=12, seed=3)
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, max_iter=12,
+                          seed=3)
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-7
+
+
+def test_handle_facts_for_measurement():
+    w = workloads.small(n=200, p=120, K=30, level_counts=(20, 5))
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.optimize([a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha, max_iter=0, seed=1)
+    for forced, path in ((0, 0), (2, 1), (3, 2)):
+        ds.set_option("col_factored", forced)
+        assert ds.info("col_stats_path") == path
+        assert ds.info("col_mfma_per_gene") > 0
+    # pair-count form: per covariate ceil(L/4) NB^2 for M += A'P, plus ceil(L/16) ceil(rows/4) NB for P = N Tab
+    assert ds.info("col_mfma_per_gene") == (5 * 4 + 2 * 2 * 2) + 2 * 4
+    assert ds.info("kp") == 32 and ds.info("stat_doubles") == 768
+    with pytest.raises(_lib.InsiderError):
+        ds.info("no_such_key")
+    ds.close()

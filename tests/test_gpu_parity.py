@@ -479,7 +479,7 @@ def test_allreduce_callback_plumbing_single_gpu(oracle):
         w = workloads.small(K=6, n=70, p=96)
         ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
         plain = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=10, seed=4)
-        ar = idist.attach(ds, 0, 0, 1, device=0, force=True)
+        ar = idist.attach(ds, 0, 0, 1, device=0, force=True, mode="torch")
         forced = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=10, seed=4)
         ds.close()
         assert np.array_equal(plain["column_factor"], forced["column_factor"])
@@ -492,6 +492,31 @@ def test_allreduce_callback_plumbing_single_gpu(oracle):
         print("all-reduce zero-copy aliasing:", ar.zero_copy)
     finally:
         dist.destroy_process_group()
+
+
+def test_in_library_rccl_allreduce_single_gpu(oracle):
+    """The in-library collective (insider_hip_comm_init: ncclAllReduce enqueued on the library's stream, no callback into
+    the host) with a one-rank RCCL communicator on the one GPU of the box: every exchange point of the sharded driver runs
+    through RCCL; a sum over one rank is the identity, so the fit equals the unsharded one bit for bit."""
+    from insider_amd import dist as idist
+    w = workloads.small(K=6, n=70, p=96)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    plain = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=10, seed=4)
+    assert idist.attach(ds, 0, 0, 1, device=0, force=True, mode="rccl") == "rccl"
+    forced = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=10, seed=4)
+    # a world > 1 handle with neither a communicator nor a callback refuses to run instead of silently skipping the sum
+    ds2 = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds2.set_shard(0, 0, 2, None)
+    with pytest.raises(_lib.InsiderError) as e:
+        ds2.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=1, seed=4)
+    assert e.value.status == _lib.ERR_COMM
+    ds2.close()
+    ds.close()
+    assert np.array_equal(plain["column_factor"], forced["column_factor"])
+    assert np.array_equal(plain["traj"], forced["traj"], equal_nan=True)
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, max_iter=10,
+                          seed=4)
+    np.testing.assert_allclose(forced["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
 
 
 @pytest.mark.parametrize("kw,m", [(dict(), 1), (dict(with_na=True), 2), (dict(tuning=0), 2), (dict(K=17, n=90, p=70), 3)])
@@ -642,7 +667,7 @@ def test_operators_reject_bad_arguments():
         ds.optimize_row(A, C, 5, lambda_=1.0)
     assert e.value.status == _lib.ERR_ARG
     with pytest.raises(_lib.InsiderError):
-        ds.optimize_row(A, C, 0, lambda_=-1.0)
+        ds.optimize_row(A, C, 0, lambda_=float("nan"))
     with pytest.raises(_lib.InsiderError):
         ds.optimize_col(A, C, tuning=2)
     ds.close()

@@ -117,3 +117,31 @@ def test_sweep_cap_terminates(oracle):
     X, y = _problem(50, 6, 9)
     beta, sweeps = oracle.strong_cd(X, y, np.zeros(6), 1.0, 0.3, X.T @ X, X.T @ y, tol=0.0, max_sweeps=7)
     assert sweeps == 7 and np.all(np.isfinite(beta))
+
+
+def test_covariance_form_variant_matches_reference_form(oracle):
+    """bench.py's labelled CPU-optimised baseline variant (covariance-form sweeps, oracle.set_cd_form(1)) walks the same
+    iterates as the reference's residual-form solver: same sweep counts, same solution; the gene-loop chunk size
+    (oracle.set_col_chunk) does not change results."""
+    from insider_amd import workloads
+    for seed, (K, lam, alpha, tol) in enumerate([(5, 2.0, 0.4, 1e-6), (30, 5.0, 0.4, 1e-5), (17, 200.0, 0.5, 1e-8)]):
+        X, y = _problem(250, K, 40 + seed)
+        G, q = X.T @ X, X.T @ y
+        w0 = np.random.default_rng(seed).standard_normal(K) * 0.1
+        b0, s0 = oracle.strong_cd(X, y, w0, lam, alpha, G, q, tol=tol, seed=3, it=seed)
+        b1, s1 = oracle.strong_cd_cov(w0, lam, alpha, G, q, tol=tol, seed=3, it=seed)
+        assert abs(s0 - s1) <= 1 and np.max(np.abs(b0 - b1)) < 1e-9
+    w = workloads.small(n=60, p=230, K=6)
+    kw = dict(tuning=1, max_iter=3, seed=5)
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, **kw)
+    try:
+        oracle.set_col_chunk(1)
+        r1 = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, **kw)
+        oracle.set_cd_form(1)
+        r2 = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, **kw)
+    finally:
+        oracle.set_col_chunk(100)
+        oracle.set_cd_form(0)
+    assert np.array_equal(r1["column_factor"], ref["column_factor"]) and r1["total_sweeps"] == ref["total_sweeps"]
+    assert np.max(np.abs(r2["column_factor"] - ref["column_factor"])) < 1e-8
+    assert abs(r2["total_sweeps"] - ref["total_sweeps"]) <= 0.01 * ref["total_sweeps"] + 2
