@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — outer-iterations/sec of the INSIDER factorisation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3] [--grid]
 
 A "step" is one outer iteration of the reference's optimize() (src/optimize.cpp:325-410): all covariate row
 updates, the column update and the amortised checkpoint work.  The timed region is ONE optimize() call of K outer
-iterations (max_iter = K-1; K = 31 is exactly a tuning_iter = 30 call of tune(), R/insider.R:163-164) with X, the
-masks and the level tables already resident in HBM; W warm-up iterations run first through a separate call.
-N > 1: one process per GPU (torchrun), genes sharded across ranks, RCCL all-reduces of the per-level normal equations
-and of the loss terms.  --scaling weak (default): every GPU holds one slab of the workload's own gene count, i.e. the
-problem is n x (p N) (N = 4 on c3 is exactly BASELINE's config c4, 10000 x 200000) and `value` = N x outer
-iterations/s of that problem (slab-iterations per second, so value(N) / (N value(1)) is the scaling efficiency).
---scaling strong: the workload's own p genes are split N ways (c3 / 8 = 6250 genes per GPU is fewer than the 12288
-the sweep kernel needs to fill one MI355X).
+iterations from fresh N(0, 1e-6) inits (max_iter = K-1; K = 31 is exactly a tuning_iter = 30 call of tune(),
+R/insider.R:163-164) with X, the masks and the level tables already resident in HBM; W warm-up iterations run first
+through a separate call at a NEIGHBOURING grid point (other lambda, other inits, other sweep seed), so the timed call
+inherits what a real tune() grid point inherits from its predecessor and not a replay of itself.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the column-side masked Gram/XtY statistics (the quantity
-BASELINE.json's metric names), timed live with HIP events on the library's stream; `cd_kernel` reports the
-elastic-net sweep kernel, which dominates wall time at these sizes; `cpu_baseline` times the CPU oracle (the
-reference's formulation) on a bounded gene sample of the same workload on this box's host cores.
+N = 1: BASELINE config 3 (10000 x 50000, K = 30).  N > 1 (one process per GPU under torchrun): BASELINE config 4
+(10000 x 200000, K = 30) STRONG-scaled — the 200000 genes are split N ways, `value` = outer iterations/s of that one
+problem; RCCL all-reduces (inside the library, on its stream) of the per-level normal equations per covariate and of the
+loss terms per checkpoint.  --workload / --scaling override both.
+
+Prints ONE JSON line on rank 0:
+  roofline      the dominant kernel pair = the column step as SURVEY.md 8d prices it (masked Gram/XtY statistics +
+                elastic-net sweeps; B_col = 8np + np + 8nK + 16Kp algorithmic bytes) against the 8 TB/s HBM peak,
+                average launch durations from HIP events on the library's stream over the timed region
+  masked_gram   the statistics kernel alone (BASELINE's metric 2) against the resource that binds it (f64 MFMA for
+                the pair-count / look-up / list forms), with its measured HBM bytes
+  cd_kernel     the sweep kernel alone
+  cpu_baseline  the CPU oracle (reference formulation) on a bounded gene sample, all host threads engaged
+  grid          (--grid) BASELINE config 3 as written: tune() over lambda in {1,3,..,19} x alpha in {.2,.3,.4,.5}
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a copy kernel)
-FP64_PEAK_TFLOPS = 78.6    # fp64 vector == fp64 matrix peak on MI355X (vendor figure)
+FP64_PEAK_TFLOPS = 78.6    # fp64 vector == fp64 matrix (v_mfma_f64_16x16x4) peak on MI355X
 
 
 def parse():
@@ -39,11 +46,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=31)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = one slab of the workload's gene count per GPU (p N genes in all); strong = p genes split N ways")
+    ap.add_argument("--workload", default=None, help="default: c3 on one GPU, c4 on several")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1: strong (default) = the workload's p genes split N ways; weak = one slab of p genes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-genes", type=int, default=0, help="0 = choose for ~10-30 s of CPU work")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the baseline sample")
+    ap.add_argument("--grid", action="store_true", help="also time tune()'s lambda x alpha grid on the resident data set (N = 1)")
     ap.add_argument("--seed", type=int, default=20240301)
     return ap.parse_args()
 
@@ -60,34 +68,122 @@ def host_cores():
     return n
 
 
-def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter):
-    """The CPU oracle (reference formulation: residual-form CD, cube slices, materialised residual) on a bounded
-    sample: the first `genes` genes of the same workload, all samples, 1 outer iteration, phases timed separately.
-    Row update, residual GEMMs and evaluation cost the reference a fixed amount per gene; the column update costs a
-    fixed amount per gene PER SWEEP (4 K n_sel flops on the residual).  The sample's own sweep count is not
-    representative (a 16-gene problem is not the 50000-gene problem), so the column phase is scaled by the sweep
-    count the full workload actually needed (measured on the GPU run above; the GPU path and the oracle run the
-    same sweeps on the same subproblem, see tests/test_gpu_parity.py)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def source_sha():
+    """Hash of the device / host sources a profile was taken on: profiles/traffic.json carries the same hash."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "insider_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
+    """The CPU oracle (the reference's formulation: materialised residual, per-covariate recomputation, cube slices,
+    residual-form CD) on a BOUNDED SAMPLE of the same workload, timed on this box's host cores.
+
+    Sample: the first G genes x all samples, one outer iteration, sweeps capped; gene-loop chunk 1 (the reference's
+    schedule(dynamic, 100) would put a G < 100 x threads sample on a few threads), so every thread is busy — the
+    record carries cpu-time / wall to show it.  Per outer iteration the reference pays a fixed cost per gene (row
+    update, the residual GEMMs, evaluation) and a cost per gene PER SWEEP (4 K n_sel flops on the residual); the
+    sample's own sweep count is not the workload's (a G-gene problem is not the 50000-gene problem), so the sweep
+    phase is scaled by the sweep count the full workload needed (measured on the GPU run; the HIP path and the
+    oracle run the same sweeps on the same subproblem, tests/test_gpu_configs.py).  Both thread settings of
+    BASELINE.md section 3 are reported, and the labelled covariance-form CPU variant separates algebra from hardware."""
     from insider_amd import workloads
     from oracle import c_oracle
     cn, cp = workloads.CONFIGS[name][0], workloads.CONFIGS[name][1]
-    genes = 3 * min(30, n_cores)      # ~10-15 s of CPU work: three waves of the column step's threads
+    settings = [("reference_threads", min(10, n_cores), min(30, n_cores))]
+    if (min(10, n_cores), min(30, n_cores)) != (n_cores, n_cores):
+        settings.append(("all_cores", n_cores, n_cores))
+    # ~0.7 ms per gene-sweep per core at c3 (4 K n_sel flops, L2-bound): size the sample for the budget
+    per_run = budget_s / (len(settings) + 0.25)
+    cap = 120
+    genes = int(max(4 * n_cores, min(64 * n_cores, per_run * n_cores / (0.7e-3 * cap * (cn / 10000.0)))))
     w = workloads.make(name, gene_range=(0, genes))
-    row_t, col_t = min(10, n_cores), min(30, n_cores)      # the reference's hard-coded 10 / 30 (src/optimize.cpp:140,376)
+    out = {}
+    c_oracle.set_col_chunk(1)
+    try:
+        # untimed pass with one sweep: page in the sample and the oracle's buffers
+        c_oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, lam, lam, alpha, tuning=w.tuning,
+                          max_iter=0, seed=1, row_threads=n_cores, col_threads=n_cores, max_sweeps=1)
+        for label, row_t, col_t in settings + [("covariance_form_variant", n_cores, n_cores)]:
+            c_oracle.set_cd_form(1 if label == "covariance_form_variant" else 0)
+            t0, c0 = time.perf_counter(), time.process_time()
+            res = c_oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, lam, lam, alpha,
+                                    tuning=w.tuning, max_iter=0, seed=1, row_threads=row_t, col_threads=col_t,
+                                    max_sweeps=cap if label != "covariance_form_variant" else 20 * cap)
+            wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+            ph = res["phase_seconds"]
+            per_gene_fixed = (ph["row"] + ph["residual_eval"]) / genes
+            per_gene_sweep = ph["col"] / max(res["total_sweeps"], 1)
+            t_iter = cp * (per_gene_fixed + per_gene_sweep * sweeps_per_gene_iter)
+            out[label] = {"value": 1.0 / t_iter, "row_threads": row_t, "col_threads": col_t,
+                          "fixed_ms_per_gene": per_gene_fixed * 1e3, "sweep_ms_per_gene_sweep": per_gene_sweep * 1e3,
+                          "sample_wall_s": wall, "sample_cpu_s": cpu, "cpu_over_wall": cpu / wall,
+                          "sample_sweeps": int(res["total_sweeps"])}
+    finally:
+        c_oracle.set_col_chunk(100)
+        c_oracle.set_cd_form(0)
+    main = out["reference_threads"]
+    return {"value": main["value"], "unit": "outer-iterations/s", "cores": main["col_threads"], "kind": "port",
+            "sample": (f"{name}: first {genes} of {cp} genes x all {cn} samples, 1 outer iteration, sweeps capped at {cap}, "
+                       f"gene-loop chunk 1; {main['sample_wall_s']:.1f} s wall, cpu-time/wall {main['cpu_over_wall']:.1f} "
+                       f"(row step {main['row_threads']} / column step {main['col_threads']} threads; the reference hard-codes "
+                       f"10 / 30, src/optimize.cpp:140,376); fixed {main['fixed_ms_per_gene']:.2f} ms/gene + "
+                       f"{main['sweep_ms_per_gene_sweep']:.4f} ms/gene/sweep, scaled to {cp} genes at "
+                       f"{sweeps_per_gene_iter:.0f} sweeps/gene/iteration (the full workload's mean, measured on the GPU run)"),
+            "cpu_model": cpu_model(), "nproc": n_cores, "omp_proc_bind": os.environ.get("OMP_PROC_BIND", "unset"),
+            "omp_places": os.environ.get("OMP_PLACES", "unset"), "settings": out,
+            "note": ("covariance_form_variant is NOT the reference's algorithm: the same oracle with covariance-form sweeps "
+                     "(2 K^2 instead of 4 K n_sel flops per sweep), reported so that the algebraic part of any GPU/CPU "
+                     "ratio can be separated from the hardware part")}
+
+
+def grid_bench(ds, w, K, steps):
+    """BASELINE config 3 as written: tune()'s lambda x alpha grid (README.md:79 of the reference: lambda in {1,3,..,19},
+    alpha in {0.2,..,0.5}) on the resident data set, tuning_iter = steps - 1, fresh inits per point (R/insider.R:142-174)."""
+    from insider_amd import api
+    obj = api.Insider()
+    obj["data"] = w.X
+    obj["confounder"] = w.levels
+    obj["inc_continuous"] = 0
+    obj["ctns_confounder"] = None
+    obj["train_indicator"], obj["test_indicator"] = w.M_train, w.M_test
+    obj["params"] = dict(global_tol=-1.0, sub_tol=1e-5, tuning_iter=steps - 1, max_iter=50000)
+    obj["seed"] = 7
+    obj["_resident_tune"] = ds
+    lambdas, alphas = list(range(1, 20, 2)), [0.2, 0.3, 0.4, 0.5]
+    timings = []
+    import contextlib
+    import io
     t0 = time.perf_counter()
-    res = c_oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, lam, lam, alpha, tuning=w.tuning,
-                            max_iter=0, seed=1, row_threads=row_t, col_threads=col_t, max_sweeps=2000)
-    dt = time.perf_counter() - t0
-    ph = res["phase_seconds"]
-    per_gene_fixed = (ph["row"] + ph["residual_eval"]) / genes
-    per_gene_sweep = ph["col"] / max(res["total_sweeps"], 1)
-    t_iter = cp * (per_gene_fixed + per_gene_sweep * sweeps_per_gene_iter)
-    return {"value": 1.0 / t_iter, "unit": "outer-iterations/s", "cores": col_t, "kind": "port",
-            "sample": f"{name}: first {genes} of {cp} genes x all {cn} samples, 1 outer iteration, {dt:.1f} s wall: "
-                      f"row+residual+eval {per_gene_fixed * 1e3:.1f} ms/gene, column update "
-                      f"{per_gene_sweep * 1e3:.3f} ms/gene/sweep over {res['total_sweeps']} sweeps; scaled to {cp} genes at "
-                      f"{sweeps_per_gene_iter:.0f} sweeps/gene/iteration (the full workload's measured mean); "
-                      f"row step {row_t} threads / column step {col_t} threads (reference hard-codes 10 / 30)"}
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = api.tune(obj, latent_dimension=np.array([K]), lambda_=lambdas, alpha=alphas, timings=timings)
+    wall = time.perf_counter() - t0
+    tab = res["reg_tuning"]
+    best = tab[int(np.argmin(tab[:, 3]))]
+    npts = len(timings)
+    return {"points": npts, "lambda": lambdas, "alpha": alphas, "iterations_per_point": steps, "wall_s": wall,
+            "mean_outer_iterations_per_s": npts * steps / wall,
+            "per_point_ms": {"init_draw": 1e3 * float(np.mean([t["init_s"] for t in timings])),
+                             "optimize_call": 1e3 * float(np.mean([t["optimize_s"] for t in timings])),
+                             "inside_library": float(np.mean([t["library_ms"] for t in timings])),
+                             "host_overhead": 1e3 * wall / npts - float(np.mean([t["library_ms"] for t in timings]))},
+            "slowest_point_ms": 1e3 * float(max(t["optimize_s"] for t in timings)),
+            "fastest_point_ms": 1e3 * float(min(t["optimize_s"] for t in timings)),
+            "best": {"lambda": float(best[0]), "alpha": float(best[1]), "test_rmse": float(best[3])},
+            "note": "host_overhead = init draw (numpy, 1.5 M normals), 2 x factor transfer over PCIe, Python; X / masks / lists stay resident"}
 
 
 def main():
@@ -120,9 +216,10 @@ def main():
         dist.barrier()
     from insider_amd import api, dist as idist, workloads
 
-    name = args.workload
+    name = args.workload or ("c3" if world == 1 else "c4")
+    scaling = args.scaling or "strong"
     n, p_total, _, _, K, lam, alpha, tuning, f = workloads.CONFIGS[name]
-    weak = args.scaling == "weak"
+    weak = scaling == "weak" and world > 1
     slabs = world if weak else 1          # weak scaling: the problem grows with the GPU count
     p_total *= slabs
     lo, hi = idist.shard_range(p_total, rank, world)
@@ -132,29 +229,45 @@ def main():
     t0 = time.perf_counter()
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, device=local_rank)
     t_up = time.perf_counter() - t0
-    idist.attach(ds, lo, rank, world, device=local_rank, staged=one_gpu)
+    if world > 1 and not one_gpu:
+        # in-library RCCL (ncclAllReduce on the library's stream); if any rank cannot join, all ranks fall back together
+        # to the torch.distributed callback
+        joined, exchange = 1, None
+        try:
+            exchange = idist.attach(ds, lo, rank, world, device=local_rank, mode="rccl")
+        except Exception as e:
+            joined = 0
+            print(f"[bench rank {rank}] in-library RCCL unavailable ({e!r}); falling back to the torch.distributed callback",
+                  file=sys.stderr, flush=True)
+        flag = torch.tensor([joined], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            exchange = idist.attach(ds, lo, rank, world, device=local_rank, mode="torch")
+    else:
+        exchange = idist.attach(ds, lo, rank, world, device=local_rank, staged=one_gpu)
     ds.set_option("profile", 1)
     p_loc = hi - lo
 
-    def fresh():
-        """Fresh copies of the N(0, 1e-6) inits: optimize() updates its factor arguments in place (like the reference)."""
-        return [a.copy(order="F") for a in w.A0], w.C0.copy(order="F")
+    def inits(seed):
+        """N(0, 1e-6) inits (R/utils.R:40-43): optimize() updates its factor arguments in place (like the reference)."""
+        A0, C0 = workloads.init_factors(w.n_levels, K, p_total, seed)
+        return A0, np.asfortranarray(C0[:, lo:hi])
 
-    def run(iters, seed, inits):
-        A, C = inits
-        return ds.optimize(A, C, K, lam, lam, alpha, tuning=tuning, max_iter=iters - 1, global_tol=-1.0, seed=seed)
+    def run(iters, seed, start, lam_):
+        A, C = start
+        return ds.optimize(A, C, K, lam_, lam_, alpha, tuning=tuning, max_iter=iters - 1, global_tol=-1.0, seed=seed)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        run(args.warmup, args.seed, fresh())
-    inits = fresh()          # host-side copies of the start values are made before the clock starts
+    if args.warmup > 0:      # a neighbouring grid point: other lambda, other inits, other sweep-order seed
+        run(args.warmup, args.seed + 1, inits(workloads.INIT_SEED + 1), lam - 2.0 if lam > 2.0 else lam + 2.0)
+    start = inits(workloads.INIT_SEED)          # host-side start values exist before the clock starts
     sync()
     t0 = time.perf_counter()
-    res = run(args.steps, args.seed, inits)
+    res = run(args.steps, args.seed, start, lam)
     sync()
     dt = time.perf_counter() - t0
     prof = ds.profile()
@@ -184,80 +297,116 @@ def main():
             return None
 
     if rank == 0:
-        gram_ms = (prof["col_stats_ms"] / max(prof["col_stats_launches"], 1))
-        # algorithmic bytes / flops of ONE launch of the masked Gram/XtY kernel over this rank's genes
-        # (SURVEY.md 8d): 8np (X) + np (uint8 mask) + 8nK (R once) + stats out; flops 2 f np K(K+1)/2 + 2 f np K
+        gram_ms = prof["col_stats_ms"] / max(prof["col_stats_launches"], 1)
+        cd_ms = prof["cd_ms"] / max(prof["cd_launches"], 1)
+        col_ms = gram_ms + cd_ms
         T = K * (K + 1) // 2
-        b_col = 8.0 * n * p_loc + 1.0 * n * p_loc + 8.0 * n * K + 8.0 * p_loc * (T + K)
-        fl = 2.0 * f * n * p_loc * T + 2.0 * f * n * p_loc * K
-        ach = b_col / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else 0.0
-        traffic = None
+        # SURVEY.md 8d, per launch over this rank's genes.  Column step with the solve fused: X + uint8 mask + R once + C in / out
+        b_col = 8.0 * n * p_loc + 1.0 * n * p_loc + 8.0 * n * K + 2.0 * 8.0 * K * p_loc
+        # statistics kernel alone (the record written out): X + mask + R + p (T + K) doubles
+        b_gram = 8.0 * n * p_loc + 1.0 * n * p_loc + 8.0 * n * K + 8.0 * p_loc * (T + K)
+        fl_alg = 2.0 * f * n * p_loc * T + 2.0 * f * n * p_loc * K
+        path = int(ds.info("col_stats_path")) if tuning == 1 else -1
+        kern = {2: "k_col_paircnt (+ k_mm_rows: held-out level sums x row factors), pair-count form",
+                1: "k_col_factored (+ k_mm_rows), look-up form", 0: "k_list_stats, one rank-one MFMA group per held-out entry",
+                -1: "none (tuning = 0: shared R'R, no masked statistics)"}[path]
+        mfma_gene = ds.info("col_mfma_per_gene") if tuning == 1 else 0.0
+        mfma_tflops = mfma_gene * p_loc * 2048.0 / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+        # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py), valid for the
+        # sources they were taken on
+        traffic, tnote = {}, "no profiles/traffic.json entry for this workload"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath)).get(name, {})
-                traffic = tj.get("pair_stats_bytes_per_launch" if prof.get("col_pair") else
-                                 "col_stats_bytes_per_launch" if prof.get("col_factored") else "list_stats_col_bytes_per_launch")
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+                ent = tj.get(name, {})
+                if ent and world == 1:
+                    same = tj.get("source_sha") == source_sha()
+                    traffic = ent
+                    tnote = (f"rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, {tj.get('command', '?')}); FETCH x 2 per "
+                             f"MI355X_MICROARCH.md; sources {'IDENTICAL to' if same else 'DIFFER from'} this run's "
+                             f"(source_sha {tj.get('source_sha')}, commit {tj.get('commit', '?')})")
+            except Exception as e:
+                tnote = f"profiles/traffic.json unreadable: {e!r}"
+        tr_stats = traffic.get("col_stats_bytes_per_launch")
+        tr_cd = traffic.get("cd_bytes_per_launch")
+        tr_col = (tr_stats + tr_cd) if (tr_stats is not None and tr_cd is not None) else None
+        cd_updates = prof["sweeps"] * K
         out = {
-            "metric": "outer-iterations/sec (masked INSIDER fit, 10k x 50k, K=30)" if name == "c3" else
-                      f"outer-iterations/sec ({name})",
+            "metric": f"outer-iterations/sec (masked INSIDER fit, {n} x {p_total}, K={K})",
             "value": slabs * args.steps / dt, "unit": "outer-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}: {n}x{p_total} fp64, K={K}, lambda={lam}, alpha={alpha}, "
                                    f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}",
                        "genes_per_gpu": p_loc, "problem_iterations_per_s": args.steps / dt,
                        "value_is": (f"{slabs} x outer iterations/s of the {n}x{p_total} problem (one {name}-sized gene slab per GPU)"
-                                    if slabs > 1 else "outer iterations/s"),
+                                    if slabs > 1 else f"outer iterations/s of the {n}x{p_total} problem"),
                        "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
-                       "parallelism": (f"gene-shard x{world}" + (" (REHEARSAL: all ranks on one GPU, host-staged all-reduce)" if one_gpu else ""))
+                       "timed_call": f"one optimize() of {args.steps} outer iterations from fresh N(0, 1e-6) inits (cold start included)",
+                       "warmup_call": "a neighbouring grid point (other lambda, inits, sweep seed)" if args.warmup > 0 else "none",
+                       "parallelism": (f"gene-shard x{world}, exchange: {exchange if isinstance(exchange, str) else type(exchange).__name__}"
+                                       + (" (REHEARSAL: all ranks on one GPU, host-staged all-reduce)" if one_gpu else ""))
                                       if world > 1 else "single GPU"},
-            "roofline": {"kernel": (("k_col_paircnt" if prof.get("col_pair") else "k_col_factored") +
-                                    " + k_mm_rows(held-out level sums x row factors): the column-side masked Gram/XtY complement "
-                                    "statistics of every gene (the quantity BASELINE's metric 2 names), " +
-                                    ("pair-count form" if prof.get("col_pair") else "look-up form"))
-                                   if prof.get("col_factored") else
-                                   "k_list_stats (masked Gram/XtY complement statistics over the held-out lists, column side)",
-                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "measured_copy_GBs": copy_bandwidth() if world == 1 else None,
-                         "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],
-                         # flops of the masked reduction as SURVEY 8d counts them (2 f n p (T + K)), not the flops executed
-                         "algorithmic_fp64_tflops": fl / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
-                         "algorithmic_fp64_frac": fl / (gram_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if gram_ms > 0 else 0.0,
-                         "row_update": "merged (per (level, gene) pair)" if prof.get("row_merged") else "per-sample statistics",
-                         "note": ("achieved = SURVEY 8d's algorithmic bytes (8np X + np mask + 8nK + 8p(T+K) out) / time. "
-                                  "The factored kernels stream neither X nor the mask (x-statistics come from per-level sums built "
-                                  "once per data set; the Gram complement costs one rank-one term per (covariate, level) plus "
-                                  "the product of the gene's dense level-pair counts with the factor table [pair-count form] or "
-                                  "one table-row add per held-out entry [look-up form]), so measured traffic is ~0.1x the "
-                                  "algorithmic bytes and achieved can exceed the HBM peak: the pair-count kernel is bound by its ~154 v_mfma_f64_16x16x4 per gene. "
-                                  "The same statistics from the per-entry list kernel (k_list_stats, option col_factored=0) "
-                                  "take 1.30 ms at c3 = 3.6 TB/s = 0.45 of peak")
-                                 if prof.get("col_factored") else
-                                 "MFMA-f64-bound: 3 v_mfma_f64_16x16x4 per 4 held-out entries (K <= 31); HBM traffic is ~0.23x the "
-                                 "algorithmic bytes (the kernel reads held-out lists, not X)"},
+            "roofline": {
+                "kernel": ("column step = masked Gram/XtY statistics [" + kern + "] + elastic-net sweeps [k_cd_cols_reg]: the "
+                           "dominant kernel pair (SURVEY.md 8d prices them as one 'column-side masked-Gram/XtY (+fused CD)' pass)"),
+                "bound": "hbm", "achieved": b_col / (col_ms * 1e-3) / 1e9 if col_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": b_col / (col_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if col_ms > 0 else 0.0,
+                "traffic": tr_col, "traffic_note": tnote,
+                "algorithmic_bytes_per_launch": b_col, "avg_launch_ms": col_ms,
+                "avg_launch_ms_parts": {"statistics": gram_ms, "sweeps": cd_ms}, "launches": prof["cd_launches"],
+                "measured_copy_GBs": copy_bandwidth() if world == 1 else None,
+                "note": ("achieved = SURVEY 8d's B_col (8np X + np mask + 8nK R + 16Kp C in/out) / (statistics + sweep kernel time), "
+                         "HIP events on the library's stream over the timed call.  The time is dominated by the sweep kernel "
+                         "(a sequential K-step recurrence per gene and sweep, hundreds to thousands of sweeps per gene in the "
+                         "first outer iterations), not by bytes: measured traffic is far below B_col because neither X nor the "
+                         "mask is streamed (held-out lists / dense level-pair counts built once per data set)")},
+            "masked_gram": {
+                "kernel": kern, "bound": "mfma", "achieved": mfma_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": mfma_tflops / FP64_PEAK_TFLOPS, "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],
+                "mfma_f64_16x16x4_per_gene": mfma_gene,
+                "traffic": tr_stats,
+                "hbm_GBs_measured": tr_stats / (gram_ms * 1e-3) / 1e9 if (tr_stats and gram_ms > 0) else None,
+                "hbm_frac_measured": tr_stats / (gram_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (tr_stats and gram_ms > 0) else None,
+                # SURVEY 8d's streaming-formulation bytes over this kernel's time: NOT a roofline fraction (the kernel does
+                # not move these bytes); kept because BASELINE's metric 2 is phrased in them
+                "algorithmic_equiv_GBs": b_gram / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else None,
+                "algorithmic_equiv_tflops": fl_alg / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else None,
+                "row_update": "merged (per (level, gene) pair)" if prof.get("row_merged") else "per-sample statistics (k_list_stats)",
+                "note": ("achieved = executed v_mfma_f64_16x16x4 flops (2048 each) / time against the 78.6 TF f64 matrix peak; the "
+                         "per-entry list form of the same statistics (option col_factored = 0) is the streaming-equivalent kernel")},
             "cd_kernel": {"kernel": "k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)",
-                          "avg_launch_ms": prof["cd_ms"] / max(prof["cd_launches"], 1),
+                          "avg_launch_ms": cd_ms, "traffic": tr_cd,
                           "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,
-                          "coordinate_updates_per_s": prof["sweeps"] * K / max(prof["cd_ms"] * 1e-3, 1e-9),
-                          # the largest share of wall time: a sequential recurrence per gene, neither HBM- nor MFMA-bound.
-                          # One coordinate step of a wave's 4 genes = 7 fp64 VALU instructions (4 cycles each on one of
-                          # 1024 SIMDs: the issue bound quoted here at the nominal 2.4 GHz) + 4 scalar instructions + one
-                          # computed jump (~4.5 ns of SIMD time, tools/ubench5/7.hip); see DESIGN.md 4.2
-                          "bound": "fp64 VALU issue, 7 instructions per coordinate step of 4 genes",
-                          "peak_updates_per_s": 1024 * 4 * 2.4e9 / (7 * 4),
-                          "frac": prof["sweeps"] * K / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * 2.4e9 / (7 * 4)),
+                          "coordinate_updates_per_s": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9),
+                          # useful arithmetic: a coordinate update is K fused multiply-adds on the gene's gradient (+ O(1))
+                          "fp64_tflops_useful": cd_updates * 2.0 * K / max(prof["cd_ms"] * 1e-3, 1e-9) / 1e12,
+                          "fp64_vector_frac": cd_updates * 2.0 * K / max(prof["cd_ms"] * 1e-3, 1e-9) / 1e12 / FP64_PEAK_TFLOPS,
+                          # the builder's own issue model (7 VALU per 4-gene coordinate step at the nominal 2.4 GHz): a
+                          # how-close-to-this-design's-ceiling figure, not a hardware roofline
+                          "valu_issue_model_updates_per_s": 1024 * 4 * 2.4e9 / (7 * 4),
+                          "valu_issue_model_frac": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * 2.4e9 / (7 * 4)),
                           "share_of_wall": prof["cd_ms"] / (dt * 1e3)},
             "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"],
             "setup_s": {"generate": t_gen, "upload_and_precompute": t_up},
         }
+        if world > 1:      # the same problem on ONE GPU, from this repository's own single-GPU run (not measured in this job)
+            try:
+                base = json.load(open(os.path.join(ROOT, "profiles", "single_gpu.json"))).get(name)
+                if base:
+                    out["config"]["single_gpu_same_problem"] = base
+            except Exception:
+                pass
+        if args.grid and world == 1:
+            try:
+                out["grid"] = grid_bench(ds, w, K, args.steps)
+            except Exception as e:
+                out["grid"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is an N = 1 figure
             try:
                 out["cpu_baseline"] = cpu_baseline(name, lam, alpha, host_cores(),
-                                                   out["cd_kernel"]["sweeps_per_gene_per_iter"])
+                                                   out["cd_kernel"]["sweeps_per_gene_per_iter"], args.cpu_seconds)
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "outer-iterations/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}

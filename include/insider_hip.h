@@ -85,8 +85,9 @@ void insider_hip_destroy(insider_hip_handle *h);
 
 /* Gene-axis sharding: this handle holds genes [gene_offset, gene_offset + p) of the global
  * matrix.  gene_offset keys the per-gene sweep order so results do not depend on the sharding.  `fn` (may be
- * NULL when world == 1) is called once per covariate per outer iteration (level normal equations) and once
- * per checkpoint (loss terms). */
+ * NULL when world == 1, or when insider_hip_comm_init() supplies the exchange) is called once per covariate per outer
+ * iteration (level normal equations) and once per checkpoint (loss terms).  A non-NULL `fn` replaces a communicator
+ * installed earlier by insider_hip_comm_init(). */
 int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, int world, insider_allreduce_fn fn,
                           void *user);
 

@@ -221,6 +221,8 @@ def optimize(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, 
     if Mtr.shape != (n, p) or Mte.shape != (n, p):
         raise InsiderError(_lib.ERR_ARG, "indicator shape must match data")
     if inc_continuous == 1:
+        if ctns_confounder is None:
+            raise InsiderError(_lib.ERR_ARG, "inc_continuous = 1 needs ctns_confounder (n x m)")
         Z = _lib.f64(np.asarray(ctns_confounder, dtype=np.float64).reshape(n, -1))
         m, zp = Z.shape[1], _lib.ptr(Z)
     else:
@@ -433,13 +435,15 @@ def _grid_sum(rows, world):
     return t.cpu().numpy()
 
 
-def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None, rank=0, world=1):
+def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None, rank=0, world=1, timings=None):
     """tune() of R/insider.R:81-176.  ``out_dir``: where to write the reference's CSVs (None = do not write).
 
     ``rank`` / ``world``: grid-parallel tuning across the GPUs of a node: every rank keeps the
     whole data set resident, grid point g is fitted by rank g % world and the result tables are summed over
     torch.distributed.  The fresh inits of ALL grid points are drawn on every rank, in the reference's order, so
-    the tables do not depend on ``world``."""
+    the tables do not depend on ``world``.  ``timings``: a list that receives one dict per fitted point
+    (init_s = drawing the fresh inits, optimize_s = the optimize() call, library_ms = time inside the library)."""
+    import time as _time
     lat = np.atleast_1d(latent_dimension) if latent_dimension is not None else np.array([])
     lam = np.atleast_1d(np.asarray(lambda_, dtype=float))
     alp = np.atleast_1d(np.asarray(alpha, dtype=float))
@@ -481,13 +485,18 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
         rows = np.zeros((len(grid), 4))
         csv = os.path.join(out_dir, f"insider_R{latent_rank}_reg_tuning_result.csv") if out_dir is not None else None
         for g, (l_r, a_r) in enumerate(grid):                                                            # :147-150
+            t_0 = _time.perf_counter()
             cfd, col = _fresh_inits(obj, latent_rank, rng)
+            t_1 = _time.perf_counter()
             if g % world != rank:
                 continue
             print(f"parameter grid: {l_r},{a_r} ---------------------------------")
             fitted = ds.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
                                  prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
                                  inc_continuous=obj["inc_continuous"])
+            if timings is not None:
+                timings.append(dict(lambda_=l_r, alpha=a_r, init_s=t_1 - t_0, optimize_s=_time.perf_counter() - t_1,
+                                    library_ms=ds.profile()["wall_ms"]))
             rows[g] = (l_r, a_r, fitted["train_rmse"], fitted["test_rmse"])
             if csv and world == 1:
                 np.savetxt(csv, rows[: g + 1], delimiter=",")

@@ -1400,7 +1400,13 @@ int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, 
                           void *user)
 {
     if (!h || world < 1 || rank < 0 || rank >= world || gene_offset < 0) return fail(INSIDER_ERR_ARG, "bad shard");
-    // world > 1 without a callback is completed by insider_hip_comm_init(); optimize() refuses to run with neither
+    // world > 1 without a callback is completed by insider_hip_comm_init(); optimize() refuses to run with neither.
+    // Installing a callback drops a communicator of an earlier insider_hip_comm_init(): the callback is then the exchange.
+    if (fn && h->comm) {
+        (void)hipSetDevice(h->device);
+        (void)ncclCommDestroy(h->comm);
+        h->comm = nullptr;
+    }
     h->gene_offset = gene_offset;
     h->rank = rank;
     h->world = world;

@@ -81,13 +81,27 @@ def test_oneshot_ex_with_continuous_covariates(oracle):
                           tuning=1, max_iter=10, seed=8, ctns=Z)
     assert relerr(Cm, ref["column_factor"]) < 1e-7 and relerr(A[-1], ref["row_matrices"][-1]) < 1e-7
     assert lo == pytest.approx(ref["loss"], rel=1e-9) and te == pytest.approx(ref["test_rmse"], rel=1e-9)
-    # the plain one-shot refuses continuous covariates with a status, it does not compute something else
+    # inc_continuous = 1 without ctns_confounder is refused with a status, at the Python mirror and at the symbol itself
     lib = _lib.load()
-    assert _raw_oneshot(w, [a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), ex=False)[0] == _lib.OK
     with pytest.raises(_lib.InsiderError) as e:
         api.optimize(w.X, w.A0, w.C0, w.levels, None, w.M_train, w.M_test, 1, w.K)
     assert e.value.status == _lib.ERR_ARG
-    assert b"ctns" in lib.insider_hip_last_error()
+    dp = C.POINTER(C.c_double)
+    A2 = [a.copy(order="F") for a in w.A0] + [U0.copy(order="F")]
+    Aptrs = (dp * len(A2))(*[a.ctypes.data_as(dp) for a in A2])
+    X = np.asfortranarray(w.X)
+    lev = np.asfortranarray(w.levels, dtype=np.int32)
+    nl = np.ascontiguousarray(w.n_levels, dtype=np.int32)
+    tr_, te_, lo_ = C.c_double(), C.c_double(), C.c_double()
+    C2 = w.C0.copy(order="F")
+    rc = lib.insider_hip_optimize_oneshot_ex(X.ctypes.data_as(dp), w.n, w.p, Aptrs, C2.ctypes.data_as(dp),
+                                             lev.ctypes.data_as(C.POINTER(C.c_int32)), lev.shape[1],
+                                             nl.ctypes.data_as(C.POINTER(C.c_int32)), None, 0,
+                                             w.M_train.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                             w.M_test.ctypes.data_as(C.POINTER(C.c_uint8)), 1, w.K, 1.0, 1.0, 0.1, 1, 1e-10,
+                                             1e-5, 3, 1, 0, C.byref(tr_), C.byref(te_), C.byref(lo_))
+    assert rc == _lib.ERR_ARG and b"ctns" in lib.insider_hip_last_error()
+    assert np.array_equal(C2, w.C0)                                  # nothing was computed
 
 
 @pytest.mark.parametrize("K,m", [(1, 2), (7, 150), (30, 9000), (40, 333)])
