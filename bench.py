@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the baseline sample")
     ap.add_argument("--grid", action="store_true", help="also time tune()'s lambda x alpha grid on the resident data set (N = 1)")
     ap.add_argument("--seed", type=int, default=20240301)
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (insider_hip_set_option), repeatable")
     return ap.parse_args()
 
 
@@ -246,6 +247,9 @@ def main():
     else:
         exchange = idist.attach(ds, lo, rank, world, device=local_rank, staged=one_gpu)
     ds.set_option("profile", 1)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ds.set_option(k, float(v))
     p_loc = hi - lo
 
     def inits(seed):
@@ -388,7 +392,7 @@ def main():
                           "valu_issue_model_updates_per_s": 1024 * 4 * 2.4e9 / (7 * 4),
                           "valu_issue_model_frac": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * 2.4e9 / (7 * 4)),
                           "share_of_wall": prof["cd_ms"] / (dt * 1e3)},
-            "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"],
+            "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"], "options": args.opt,
             "setup_s": {"generate": t_gen, "upload_and_precompute": t_up},
         }
         if world > 1:      # the same problem on ONE GPU, from this repository's own single-GPU run (not measured in this job)

@@ -113,7 +113,10 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * entry, 2 = per-(covariate, level) terms with one table look-up per entry, 3 = per-(covariate, level) terms from the
  * gene's dense level-pair counts [falls back to 2 when a count exceeds one byte]; same results), "row_counts" (1, default = the merged row update takes its per-gene level sums from the dense
  * level-pair counts when they exist, 0 = from the entry lists; same results), "force_allreduce" (1 = call the all-reduce callback even
- * when world == 1: plumbing rehearsal). */
+ * when world == 1: plumbing rehearsal), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
+ * cd_cold_iters outer iterations of a call [default 3]: the register-resident sweep kernel stops at sweep cd_pass1 [64; 0 = one
+ * pass], cd_pass1 x ratio [4], ..., re-packing the genes still running by their estimated remaining length between passes;
+ * the iterates are bit-identical to the single-pass solve). */
 int insider_hip_set_option(insider_hip_handle *h, const char *name, double value);
 
 /*
@@ -231,6 +234,11 @@ int insider_hip_get_profile(insider_hip_handle *h, double *out12);
  * (v_mfma_f64_16x16x4 instructions the column-side statistics kernel issues per gene), "row_merged", "col_entries",
  * "row_entries" (padded held-out list lengths), "lists_bytes", "pair_count_bytes_per_gene", "stat_doubles", "kp". */
 int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out);
+
+/* Diagnostics: copy an internal per-gene array to the host: "cd_pass_slot" (uint32 x p: what the last limited pass of a
+ * multi-pass column solve left per gene: 0xFFFFFFFF = finished, else estimate bucket << 24 | rank), "gene_perm" (int32 x p:
+ * the launch order). */
+int insider_hip_get_array(insider_hip_handle *h, const char *name, void *out, int64_t bytes);
 
 /* Diagnostics: per-gene sweep counts of the last column update (p ints), and the HIP-event time in ms of the
  * kernel launched by the calling THREAD's last insider_hip_strong_cd() / _xy(). */

@@ -175,6 +175,12 @@ class InsiderData:
         buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         _lib.check(_lib.load().insider_hip_comm_init(self._h, buf, int(rank), int(world)))
 
+    def debug_array(self, name):
+        """An internal per-gene int32 array (insider_hip_get_array): "cd_key0", "cd_key1", "gene_perm"."""
+        out = np.zeros(self.p, dtype=np.int32)
+        _lib.check(_lib.load().insider_hip_get_array(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
     def sweeps(self):
         """Per-gene sweep counts of the last column update."""
         out = np.zeros(self.p, dtype=np.int32)

@@ -169,7 +169,7 @@ __device__ __forceinline__ void reg_gemv(double (&acc)[SLOTS], const double (&v)
 // LDS doubles per wave: per lane and slot D = XtX_kk + l2, the sweep-start beta and w = beta D - h, and the solution
 // (values that are not needed inside the sweep live here so that the registers hold only the Gram columns and the
 // sweep state)
-constexpr int REG_STASH = 4 * 2 * 64;
+constexpr int REG_STASH = 5 * 2 * 64;   // + two 64-entry windows of |loss change| sums (multi-pass: remaining-length estimate)
 
 // The solver.  G: columns 16u + i of the row's Gram matrix (zero diagonal).  q, Gll, beta: coordinate 16u + i of
 // gene `row`; beta = warm start in, solution out.  gene_ok: the row holds a gene.  stash: this wave's REG_STASH
@@ -178,10 +178,17 @@ constexpr int REG_STASH = 4 * 2 * 64;
 // Xty - XtX beta) the exact change is sum_l [-1/2 db (g0 + g1) + 1/2 l2 (b1^2 - b0^2) + la (|b1| - |b0|)]
 // = sum_l [1/2 db (w0 + w1) + la (|b1| - |b0|)],  w = beta (XtX_kk + l2) - h;  the end values of one sweep are the
 // start values of the next.  Lanes without a coordinate carry h = beta = 0 and contribute nothing.
+// Multi-pass (P.sweep_limit / P.start_sweep): with `resume` the row continues a solve that an earlier pass stopped at sweep
+// P.start_sweep — hs / is hold its saved h and 1/D-or-0, beta its saved iterate, and nothing is re-derived (the loss
+// bookkeeping values beta0 = beta, w0 = beta D - h are the ones the single-pass solve would hold at that sweep), so the
+// iterates are bit-identical to an uninterrupted solve.  A row still running when the pass ends at P.sweep_limit returns
+// unfinished = true with its state in hs / is / beta and `key` = its estimated remaining sweeps (from the geometric decay
+// of the loss change over the last two 8-sweep windows; > 0).
 template <int SLOTS, int KMAX>
 __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, const double (&q)[SLOTS],
                                       const double (&Gll)[SLOTS], double (&beta)[SLOTS], bool gene_ok, const CdParams &P,
-                                      int lane, double *stash)
+                                      int lane, double *stash, bool resume, double (&hs)[SLOTS], double (&is)[SLOTS],
+                                      bool &unfinished, int &key)
 {
     const int row = lane >> 4, i = lane & 15;
     // the scalars the sweep loop needs, copied out of the kernel-argument tuple: the sweep's assembly clobbers s63-s99,
@@ -195,24 +202,41 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
 #endif
     const uint64_t rowmask = 0xffffull << (16 * row);
     double *s_d = stash + lane, *s_b = s_d + 128, *s_w = s_d + 256, *s_out = s_d + 384;   // [slot * 64]
-    // ---- strong rule and start values (:74-80) ---------------------------------------------------------------
-    double aq = 0.0;
-#pragma unroll
-    for (int u = 0; u < SLOTS; ++u) aq = fmax(aq, (gene_ok && 16 * u + i < K) ? fabs(q[u]) : 0.0);
-    const double thr = P.alpha * (2.0 * P.lambda - row16_max(aq));                        // :74
+    double *s_acc = s_d + 512;                                                           // [window * 64]
+    s_acc[0] = 0.0;
+    s_acc[64] = 0.0;
+    unfinished = false;
+    key = 0;
     RegState<SLOTS> S;
+    if (!resume) {
+        // ---- strong rule and start values (:74-80) -----------------------------------------------------------
+        double aq = 0.0;
 #pragma unroll
-    for (int u = 0; u < SLOTS; ++u) {
-        const bool valid = gene_ok && 16 * u + i < K;
-        const bool active = valid && !(fabs(q[u]) < thr);
-        const double D = (valid ? Gll[u] : 1.0) + l2;
-        S.beta[u] = active ? beta[u] : 0.0;                                               // :78
-        S.inv[u] = active ? cd_rcp(D) : 0.0;
-        S.h[u] = valid ? q[u] : 0.0;
-        s_d[64 * u] = D;
-        s_out[64 * u] = S.beta[u];
+        for (int u = 0; u < SLOTS; ++u) aq = fmax(aq, (gene_ok && 16 * u + i < K) ? fabs(q[u]) : 0.0);
+        const double thr = P.alpha * (2.0 * P.lambda - row16_max(aq));                    // :74
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const bool valid = gene_ok && 16 * u + i < K;
+            const bool active = valid && !(fabs(q[u]) < thr);
+            const double D = (valid ? Gll[u] : 1.0) + l2;
+            S.beta[u] = active ? beta[u] : 0.0;                                           // :78
+            S.inv[u] = active ? cd_rcp(D) : 0.0;
+            S.h[u] = valid ? q[u] : 0.0;
+            s_d[64 * u] = D;
+            s_out[64 * u] = S.beta[u];
+        }
+        reg_gemv<SLOTS, KMAX>(S.h, S.beta, G, K);                                         // :79 h = q - offdiag(XtX) beta
+    } else {
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {   // the state a limited pass saved: no screening, no re-derivation
+            const bool valid = gene_ok && 16 * u + i < K;
+            S.beta[u] = valid ? beta[u] : 0.0;
+            S.inv[u] = valid ? is[u] : 0.0;
+            S.h[u] = valid ? hs[u] : 0.0;
+            s_d[64 * u] = (valid ? Gll[u] : 1.0) + l2;
+            s_out[64 * u] = S.beta[u];
+        }
     }
-    reg_gemv<SLOTS, KMAX>(S.h, S.beta, G, K);                                             // :79 h = q - offdiag(XtX) beta
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         s_b[64 * u] = S.beta[u];
@@ -223,9 +247,18 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
     // changed only in the rarely taken finishing path), the sweep number and the order-table pointer.  Per sweep the
     // control costs one vector compare (the convergence test) and scalar mask arithmetic.
     uint64_t runm = __ballot(gene_ok);
-    int sweep = 0, my_sweeps = 0;
-    const uint32_t *tb = reinterpret_cast<const uint32_t *>(order + REG_ORDER_OFF);
-    while (runm != 0 && sweep < max_sweeps) {   // the sweep cap is the loop bound: genes still running then are parked below
+    int sweep = P.start_sweep, my_sweeps = 0;
+    int stop = (P.sweep_limit > 0 && P.sweep_limit < max_sweeps) ? P.sweep_limit : max_sweeps;
+    // a limited pass sums |loss change| over its last two windows of W sweeps (W = a quarter of the pass, at least 8: the
+    // per-sweep change fluctuates with the random coordinate order, a slow decay needs a long window to show)
+    int W = (stop - sweep) >> 2;
+    W = W < 8 ? 8 : W;
+    const int win = stop < max_sweeps ? stop - 2 * W : max_sweeps;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(sweep), "+s"(stop));
+#endif
+    const uint32_t *tb = reinterpret_cast<const uint32_t *>(order + (size_t)sweep * ORDER_ROW + REG_ORDER_OFF);
+    while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
         reg_sweep(S, G, la, tb);
         tb += ORDER_ROW / 4;
@@ -242,6 +275,7 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             s_w[64 * u] = w1;
         }
         const double dloss = row16_sum(fma(la, acc1, 0.5 * acc));
+        if (sweep > win) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);                   // wave-uniform, limited passes only
         const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
         if (cand != 0) {                                                                    // wave-uniform, rarely taken
             const bool mine = (cand >> lane) & 1ull;
@@ -267,10 +301,21 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             runm &= ~__ballot(finish);
         }
     }
-    if ((runm >> lane) & 1ull) {   // stopped by the sweep cap
+    if ((runm >> lane) & 1ull) {   // stopped by the sweep cap, or by the end of a limited pass
         my_sweeps = sweep;
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) s_out[64 * u] = S.beta[u];
+        if (sweep < max_sweeps) {   // to be continued by the next pass
+            unfinished = true;
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) { hs[u] = S.h[u]; is[u] = S.inv[u]; }
+            // |loss change| decays geometrically: rho^W = b / a over the last two W-sweep windows; sweeps until it reaches tol
+            const double wa = s_acc[0], wb = s_acc[64], wt = (double)W * tol;
+            double est = 1048576.0;
+            if (wa > wb && wb > wt) est = (double)W * log(wb / wt) / log(wa / wb);
+            else if (wb <= wt) est = 1.0;
+            key = (int)fmin(fmax(est, 1.0), 1048576.0);
+        }
     }
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) beta[u] = (gene_ok && 16 * u + i < K) ? s_out[64 * u] : 0.0;
@@ -288,7 +333,10 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
     const int K = a.K, KP = a.KP;
     const int slot = blockIdx.x * 4 + row;
     const int j = slot < a.p ? (a.gene_perm ? a.gene_perm[slot] : slot) : a.p;
-    const bool gene = j < a.p;
+    // a resumed pass (multi-pass solve) continues the genes the previous pass left unfinished: the first *pass_count of its order
+    const bool resume = a.pass_count != nullptr;
+    const bool gene = j < a.p && (!resume || slot < *a.pass_count);
+    if (resume && __ballot(gene) == 0) return;
     __shared__ double stash[REG_STASH];
     const double *st = (a.stat && gene) ? a.stat + (size_t)j * a.stat_len : nullptr;
     // XtX_j = R'R - complement (src/optimize.cpp:218-219: the statistics record holds it ready-made), or the shared R'R
@@ -317,14 +365,37 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
             beta[u] = a.C[(size_t)j * KP + c];
         }
     }
+    bool done = gene;      // the rows whose solve ends in this launch: they own the results and the loss statistics
     if (a.mode == COL_CD) {                                                              // :228,246
-        const int sweeps = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, gene, a.cd, lane, stash);
+        double hs[SLOTS], is[SLOTS];
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const bool ld = resume && gene && 16 * u + i < K;
+            hs[u] = ld ? a.hsave[(size_t)j * KP + 16 * u + i] : 0.0;
+            is[u] = ld ? a.isave[(size_t)j * KP + 16 * u + i] : 0.0;
+        }
+        bool unfinished;
+        int key;
+        const int sweeps = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, gene, a.cd, lane, stash, resume, hs, is, unfinished, key);
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u)
-            if (gene && 16 * u + i < K) a.C[(size_t)j * KP + 16 * u + i] = beta[u];
+            if (gene && 16 * u + i < K) {
+                a.C[(size_t)j * KP + 16 * u + i] = beta[u];
+                if (unfinished) {
+                    a.hsave[(size_t)j * KP + 16 * u + i] = hs[u];
+                    a.isave[(size_t)j * KP + 16 * u + i] = is[u];
+                }
+            }
+        done = gene && !unfinished;
         if (gene && i == 0) {
-            a.sweeps[j] = sweeps;
-            if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
+            if (unfinished) {
+                const int b = cd_bucket(key);
+                a.pass_slot[j] = ((uint32_t)b << 24) | (uint32_t)atomicAdd(&a.bucket_cnt[b], 1);
+            } else {
+                if (a.pass_slot) a.pass_slot[j] = CD_PASS_DONE;
+                a.sweeps[j] = sweeps;
+                if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
+            }
         }
     }
     if (!a.checkpoint) return;
@@ -357,7 +428,7 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
         }
     }
     const double bqg = row16_sum(t_bqg), sb2 = row16_sum(t_b2), sb1 = row16_sum(t_b1), te = row16_sum(t_te);
-    if (gene && i == 0) {
+    if (done && i == 0) {
         a.sse_train[j] = a.yy[j] - bqg;
         a.b2[j] = sb2;
         a.b1[j] = sb1;
@@ -392,7 +463,10 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
         q[u] = ok ? Xty[(size_t)b * K + c] : 0.0;
         beta[u] = ok ? wstart[(size_t)b * K + c] : 0.0;
     }
-    const int sw = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, prob, cd, lane, stash);
+    double hs[SLOTS], is[SLOTS];
+    bool unfinished;
+    int key;
+    const int sw = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, prob, cd, lane, stash, false, hs, is, unfinished, key);
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u)
         if (prob && 16 * u + i < K) beta_out[(size_t)b * K + 16 * u + i] = beta[u];

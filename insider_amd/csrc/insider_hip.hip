@@ -162,6 +162,12 @@ struct insider_hip_handle {
     int order_rows = 0;
     // gene scheduling for the CD kernel: genes sorted by the sweep count of their previous solve
     int *gene_ids = nullptr, *gene_perm = nullptr, *sweeps_sorted = nullptr;
+    // multi-pass column solves in the cold outer iterations (CdParams::sweep_limit): saved state of the unfinished genes,
+    // their estimated remaining lengths (two buffers, alternating between passes) and the order of the next pass
+    double *cd_hsave = nullptr, *cd_isave = nullptr;
+    uint32_t *cd_pass_slot = nullptr;
+    int *cd_pass_perm[2] = {nullptr, nullptr}, *cd_pass_cnt = nullptr;   // cd_pass_cnt: CD_BUCKETS counters + 2 list lengths
+    int cd_cold_iters = 3, cd_pass_first = 64, cd_pass_ratio = 4;   // options "cd_cold_iters", "cd_pass1" (0 = single pass), "cd_pass_ratio"
     // longest-first gene orders of outer iterations 0..2 of the previous optimize() on this handle: the early iterations
     // of the next call (tune()'s next grid point) have similar per-gene sweep counts, its later ones do not
     static constexpr int EARLY = 3;
@@ -203,8 +209,14 @@ void free_workspace(insider_hip_handle *h)
     if (h->order) (void)hipFree(h->order);
     h->order = nullptr;
     h->order_rows = 0;
-    for (void *q : {(void *)h->gene_ids, (void *)h->gene_perm, (void *)h->sweeps_sorted, h->sort_tmp}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)h->gene_ids, (void *)h->gene_perm, (void *)h->sweeps_sorted, h->sort_tmp, (void *)h->cd_hsave,
+                    (void *)h->cd_isave, (void *)h->cd_pass_slot, (void *)h->cd_pass_perm[0], (void *)h->cd_pass_perm[1],
+                    (void *)h->cd_pass_cnt})
+        if (q) (void)hipFree(q);
     h->gene_ids = h->gene_perm = h->sweeps_sorted = nullptr;
+    h->cd_hsave = h->cd_isave = nullptr;
+    h->cd_pass_slot = nullptr;
+    h->cd_pass_perm[0] = h->cd_pass_perm[1] = h->cd_pass_cnt = nullptr;
     for (int e = 0; e < insider_hip_handle::EARLY; ++e) {
         if (h->perm_early[e]) (void)hipFree(h->perm_early[e]);
         h->perm_early[e] = nullptr;
@@ -277,6 +289,12 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sweeps_sorted, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sweep_key, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->cd_hsave, (size_t)h->p * KP))) return rc;
+    if ((rc = dmalloc(&h->cd_isave, (size_t)h->p * KP))) return rc;
+    if ((rc = dmalloc(&h->cd_pass_slot, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->cd_pass_perm[0], (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->cd_pass_perm[1], (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->cd_pass_cnt, (size_t)CD_BUCKETS + 2))) return rc;
     for (int e = 0; e < insider_hip_handle::EARLY; ++e)
         if ((rc = dmalloc(&h->perm_early[e], (size_t)h->p))) return rc;
     {
@@ -583,9 +601,44 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.gene_perm = !solve ? nullptr : (early && h->have_early[outer_iter]) ? h->perm_early[outer_iter]
                                        : h->have_perm                         ? h->gene_perm
                                                                               : nullptr;
+        a.hsave = h->cd_hsave;
+        a.isave = h->cd_isave;
+        a.pass_count = nullptr;
+        a.pass_slot = nullptr;
+        a.bucket_cnt = nullptr;
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
         if (h->cd_variant == 0 && h->K <= 32) {
-            REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a));
+            // Cold outer iterations: thousands of sweeps per gene whose counts no history predicts, so a wave's four genes
+            // finish far apart (measured at c3: 1.17x / 1.44x / 2.1x the ideal wave time in outer iterations 0 / 1 / 2).
+            // The solve then runs in passes over geometrically growing sweep ranges: a limited pass stops at its sweep
+            // index, the genes still running save their state and an estimate of their remaining length (from the decay
+            // of the loss change), k_pass_scatter groups them by that estimate, and the next pass continues them
+            // bit-identically in waves of similar length (insider_cd_reg.hpp).  A pass with nothing left exits at once.
+            int limits[16], npass = 0;
+            if (solve && outer_iter >= 0 && outer_iter < h->cd_cold_iters && h->cd_pass_first >= 32)
+                for (int64_t l = h->cd_pass_first; l < h->max_sweeps && npass < 16; l *= std::max(h->cd_pass_ratio, 2))
+                    limits[npass++] = (int)l;
+            int start = 0;
+            const int *perm_in = a.gene_perm;
+            for (int pass = 0;; ++pass) {
+                const int limit = pass < npass ? limits[pass] : 0;
+                a.cd.start_sweep = start;
+                a.cd.sweep_limit = limit;
+                a.pass_slot = npass ? h->cd_pass_slot : nullptr;
+                a.bucket_cnt = limit ? h->cd_pass_cnt : nullptr;
+                if (limit) HIPCHECK(hipMemsetAsync(h->cd_pass_cnt, 0, CD_BUCKETS * sizeof(int), h->stream));
+                REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a));
+                KCHECK();
+                if (!limit) break;
+                int *count_out = h->cd_pass_cnt + CD_BUCKETS + (pass & 1);
+                hipLaunchKernelGGL(k_pass_scatter, dim3(cdiv(h->p, 256)), dim3(256), 0, h->stream,
+                                   (const uint32_t *)h->cd_pass_slot, (const int *)h->cd_pass_cnt, perm_in, a.pass_count, (int)h->p,
+                                   h->cd_pass_perm[pass & 1], count_out);
+                KCHECK();
+                perm_in = a.gene_perm = h->cd_pass_perm[pass & 1];
+                a.pass_count = count_out;
+                start = limit;
+            }
         } else if (h->cd_variant == 2 && h->K <= 16)
             hipLaunchKernelGGL((k_cd_cols_r16<1>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
         else if (h->cd_variant == 2 && h->K <= 32)
@@ -1451,6 +1504,9 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "col_factored") h->col_factored = (int)value;   // 1 = cost model picks list / look-up / pair-count form (default), 2 = look-up form, 3 = pair-count form, 0 = k_list_stats
     else if (s == "row_counts") h->row_counts = (int)value;   // 1 = the merged row update takes u from the dense pair counts when they exist (default), 0 = from the entry lists
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
+    else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
+    else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
+    else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
@@ -1942,6 +1998,22 @@ int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out)
             }
         *out = v;
     } else return fail(INSIDER_ERR_ARG, "unknown info key " + s);
+    return INSIDER_OK;
+}
+
+int insider_hip_get_array(insider_hip_handle *h, const char *name, void *out, int64_t bytes)
+{
+    if (!h || !name || !out) return fail(INSIDER_ERR_ARG, "null");
+    const std::string s(name);
+    const void *src = nullptr;
+    int64_t have = 0;
+    if (s == "cd_pass_slot") { src = h->cd_pass_slot; have = h->p * (int64_t)sizeof(int); }
+    else if (s == "gene_perm") { src = h->gene_perm; have = h->p * (int64_t)sizeof(int); }
+    else return fail(INSIDER_ERR_ARG, "unknown array " + s);
+    if (!src || bytes > have) return fail(INSIDER_ERR_ARG, "array not available or too short");
+    HIPCHECK(hipSetDevice(h->device));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpy(out, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return INSIDER_OK;
 }
 

@@ -196,6 +196,10 @@ struct CdParams {
     double la, l2;          // lambda * alpha, lambda * (1 - alpha): formed on the host so that they arrive in SGPRs
     int max_sweeps;
     const uint8_t *order;   // [max_sweeps][ORDER_ROW], see k_order_table
+    // multi-pass solves (register-resident kernel, cold outer iterations): a pass covers sweeps [start_sweep, sweep_limit);
+    // genes still running at sweep_limit save their state (beta, h, 1/D or 0) and are re-packed, by predicted remaining
+    // length, into the waves of the next pass, which continues them bit-identically.  sweep_limit == 0: run to the end.
+    int start_sweep = 0, sweep_limit = 0;
 };
 
 // 1 / (XtX_kk + lambda (1 - alpha)) of src/coordinate_descent.cpp:99-104.  A zero denominator means the coordinate's
@@ -652,7 +656,39 @@ struct ColArgs {
     int *sweeps;             // p
     unsigned long long *sweep_bins;   // 256 counters: total sweeps of the launch, spread to keep the atomics cheap
     const int *gene_perm;    // launch slot -> gene (genes sorted by their last sweep count, longest first), or null
+    // multi-pass solves (CdParams::sweep_limit / start_sweep)
+    double *hsave, *isave;       // p x KP each: h and 1/D-or-0 of the genes a limited pass left unfinished
+    const int *pass_count;       // resumed pass: number of genes to continue = the first *pass_count entries of gene_perm; else null
+    uint32_t *pass_slot;         // limited pass, per gene it processed: CD_PASS_DONE, or (bucket << 24 | rank in the bucket) of a gene it
+                                 // leaves unfinished (bucket = its estimated remaining sweeps on a log scale, see k_pass_scatter)
+    int *bucket_cnt;             // limited pass: CD_BUCKETS counters (zeroed by the host)
 };
+
+constexpr int CD_BUCKETS = 192;                  // 8 per octave of the estimate (1 .. 2^20 sweeps), longest first
+constexpr uint32_t CD_PASS_DONE = 0xFFFFFFFFu;
+__device__ __forceinline__ int cd_bucket(int est) { return CD_BUCKETS - 1 - min(CD_BUCKETS - 1, (int)(8.0f * __log2f((float)max(est, 1)))); }
+
+// Between two passes of a multi-pass solve: the genes the pass left unfinished, grouped by bucket (longest estimate first;
+// the order inside a bucket is the order of the atomics, which only decides which genes share a wave, never a result),
+// become the first *count_out entries of perm_out.  n_in: genes the pass processed (*count_in when it was itself resumed).
+__global__ void __launch_bounds__(256) k_pass_scatter(const uint32_t *__restrict__ pass_slot, const int *__restrict__ bucket_cnt,
+                                                      const int *__restrict__ perm_in, const int *__restrict__ count_in, int p,
+                                                      int *__restrict__ perm_out, int *__restrict__ count_out)
+{
+    __shared__ int off[CD_BUCKETS];
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < CD_BUCKETS; ++b) { off[b] = run; run += bucket_cnt[b]; }
+        if (blockIdx.x == 0) *count_out = run;
+    }
+    __syncthreads();
+    const int n_in = count_in ? *count_in : p;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n_in) return;
+    const int j = perm_in ? perm_in[slot] : slot;
+    const uint32_t v = pass_slot[j];
+    if (v != CD_PASS_DONE) perm_out[off[v >> 24] + (int)(v & 0xFFFFFFu)] = j;
+}
 
 template <int W, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_cd_cols(ColArgs a)

@@ -315,6 +315,38 @@ def test_optimize_options(oracle, opts):
     assert relerr(got["column_factor"], ref["column_factor"]) < 1e-7
 
 
+@pytest.mark.parametrize("K,limits", [(12, (32, 2)), (30, (32, 3)), (20, (64, 2)), (7, (32, 16))])
+def test_multipass_column_solve_is_bit_identical(oracle, K, limits):
+    """Cold outer iterations solve in passes (options cd_pass1 / cd_pass_ratio / cd_cold_iters, insider_cd_reg.hpp): a limited
+    pass stops at a sweep index, the unfinished genes are re-packed by estimated remaining length and continued from their
+    saved state.  The iterates must not depend on it: factors, trajectory and sweep counts bit-identical to the single-pass
+    solve (cd_pass1 = 0), and parity with the oracle."""
+    w = workloads.small(K=K, n=120, p=333, f=0.2, seed=K)          # tight tolerance below: hundreds of sweeps per gene
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.set_option("profile", 1)
+    ds.set_option("cd_pass1", 0)                                    # single-pass solves
+    kw = dict(tuning=1, max_iter=4, sub_tol=1e-11, seed=9)
+    ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=0, sub_tol=1e-11, seed=9)
+    assert ds.sweeps().max() > limits[0] + 16, ds.sweeps().max()    # the first pass really stops solves half-way
+    one = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, **kw)
+    sw_one, tot_one = ds.sweeps(), ds.profile()["sweeps"]
+    ds.set_option("cd_cold_iters", 100)
+    ds.set_option("cd_pass1", limits[0])
+    ds.set_option("cd_pass_ratio", limits[1])
+    multi = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, **kw)
+    sw_multi, tot_multi = ds.sweeps(), ds.profile()["sweeps"]
+    ds.close()
+    assert np.array_equal(one["column_factor"], multi["column_factor"])
+    assert np.array_equal(one["traj"], multi["traj"], equal_nan=True)
+    for i in range(len(w.A0)):
+        assert np.array_equal(one["row_matrices"][f"factor{i}"], multi["row_matrices"][f"factor{i}"])
+    assert np.array_equal(sw_one, sw_multi) and tot_one == tot_multi
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                          max_iter=4, sub_tol=1e-11, seed=9)
+    assert relerr(multi["column_factor"], ref["column_factor"]) < 1e-6
+    assert abs(tot_multi - ref["total_sweeps"]) <= max(3, 0.002 * ref["total_sweeps"])
+
+
 def test_sweep_counts_match_oracle(oracle):
     w = workloads.small(K=12, n=80, p=64)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
