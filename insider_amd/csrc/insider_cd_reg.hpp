@@ -146,7 +146,7 @@ __device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][1
 }
 
 // waves per SIMD the register budget of an instantiation is sized for (512 VGPRs per SIMD lane)
-__host__ __device__ constexpr int reg_waves(int KMAX) { return KMAX <= 16 ? 4 : KMAX <= 22 ? 4 : 3; }
+__host__ __device__ constexpr int reg_waves(int KMAX) { return KMAX <= 20 ? 4 : 3; }
 // smallest instantiated KMAX >= K
 __host__ __device__ constexpr int reg_kmax(int K) { return K <= 16 ? 16 : (K + 1) & ~1; }
 

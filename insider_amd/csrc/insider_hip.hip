@@ -105,6 +105,8 @@ struct insider_hip_handle {
     // the weighted SYRK of the merged row update depends on C only: all covariates' level sums are formed on a second
     // side stream while the main stream computes V, u and U'C
     hipStream_t side2 = nullptr;
+    hipStream_t side3 = nullptr;      // C'C and (S^train C') of the merged row update, next to the weighted SYRK
+    hipEvent_t ev_prep = nullptr;
     hipEvent_t ev_c_ready = nullptr;
     std::vector<hipEvent_t> ev_w;
     double *lvl_sum_all = nullptr;    // [SLcat][STAT + 2 KP + 2]: the level records of every covariate
@@ -767,9 +769,13 @@ int launch_wsyrk_side(insider_hip_handle *h)
 {
     HIPCHECK(hipEventRecord(h->ev_c_ready, h->stream));
     HIPCHECK(hipStreamWaitEvent(h->side2, h->ev_c_ready, 0));
-    // C'C and (S^train C') too (launch_row_prep): first read by k_level_reduce, i.e. after the wait for ev_w[0]
-    if (int rp = launch_gram(h, h->C, h->p, h->CCt, h->side2, h->gram_part2)) return rp;
-    if (int rp = launch_mm_reduce_kp(h, h->Strain, h->SLP, h->C, (int)h->p, h->SL, h->sc_part2, h->SC, h->side2)) return rp;
+    // The weighted SYRK of the first covariate is the longest kernel of the row phase (MFMA-bound on its (level, gene)
+    // pairs) and the first thing the main chain waits for: it starts at once.  C'C and (S^train C') (launch_row_prep) run on
+    // a third stream: they are first read by k_level_reduce, which waits for ev_prep.
+    HIPCHECK(hipStreamWaitEvent(h->side3, h->ev_c_ready, 0));
+    if (int rp = launch_gram(h, h->C, h->p, h->CCt, h->side3, h->gram_part2)) return rp;
+    if (int rp = launch_mm_reduce_kp(h, h->Strain, h->SLP, h->C, (int)h->p, h->SL, h->sc_part2, h->SC, h->side3)) return rp;
+    HIPCHECK(hipEventRecord(h->ev_prep, h->side3));
     for (int i = 0; i < h->c; ++i) {
         const CovTables &ct = h->cov[i];
         NB_DISPATCH(h->NB, {
@@ -840,7 +846,10 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
         KCHECK();
         // Y = U'C, the same reduction over genes as (S C')
         if (int rcy = launch_mm_reduce_kp(h, h->U, LP, h->C, (int)h->p, L, h->sc_part, h->Ylvl)) return rcy;
-        if (h->w_ready) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[i], 0));   // wsyrk + level sums came from side2
+        if (h->w_ready) {   // wsyrk + level sums came from side2, C'C and (S^train C') from side3
+            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[i], 0));
+            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
+        }
         NB_DISPATCH(h->NB, {
             constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
             double *rec = h->w_ready ? h->lvl_sum_all + (size_t)h->lvl_off[i] * PLEN : h->lvl_sum;
@@ -1068,6 +1077,8 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (h->cf_cnt) (void)hipFree(h->cf_cnt);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->side3) (void)hipStreamDestroy(h->side3);
+    if (h->ev_prep) (void)hipEventDestroy(h->ev_prep);
     if (h->ev_c_ready) (void)hipEventDestroy(h->ev_c_ready);
     if (h->ev_a_ready) (void)hipEventDestroy(h->ev_a_ready);
     if (h->ev_qfull) (void)hipEventDestroy(h->ev_qfull);
@@ -1128,6 +1139,8 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     CH(hipStreamCreate(&h->stream));
     CH(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     CH(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    CH(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
+    CH(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_a_ready, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_qfull, hipEventDisableTiming));
@@ -1523,6 +1536,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     // work a failed earlier call may have left on the side streams must not race with this call's
     HIPCHECK(hipStreamSynchronize(h->side));
     HIPCHECK(hipStreamSynchronize(h->side2));
+    HIPCHECK(hipStreamSynchronize(h->side3));
     if ((rc = ensure_workspace(h, K))) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     clear_events(h);
@@ -1623,6 +1637,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     if ((rc = download_factors(h, A, C, K))) return rc;
     if ((rc = check_fail_flag(h))) return rc;
     HIPCHECK(hipStreamSynchronize(h->side2));
+    HIPCHECK(hipStreamSynchronize(h->side3));
     HIPCHECK(hipStreamSynchronize(h->side));   // the gene orders kept for the next call
     h->side_pending = false;
     {
@@ -1671,6 +1686,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamSynchronize(h->side);
         (void)hipStreamSynchronize(h->side2);
+        (void)hipStreamSynchronize(h->side3);
         h->side_pending = h->qfull_pending = h->w_ready = false;
         if (h->failflag) (void)hipMemset(h->failflag, 0, 2 * sizeof(int));
         clear_events(h);

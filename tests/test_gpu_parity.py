@@ -158,7 +158,7 @@ def test_strong_cd_every_register_kernel_instantiation(oracle, K):
         assert np.array_equal(ob == 0, beta[b] == 0)          # identical sparsity pattern
 
 
-@pytest.mark.parametrize("K", [17, 19, 22, 25, 28, 31])
+@pytest.mark.parametrize("K", [16, 17, 19, 21, 22, 24, 25, 28, 30, 31])
 def test_optimize_column_kernel_instantiations(oracle, K):
     w = workloads.small(K=K, n=90, p=75, seed=K, f=0.2)
     A, C = _cp(w)
