@@ -490,22 +490,36 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
         grid = [(round(float(l_), 2), round(float(a_), 2)) for a_ in alp for l_ in lam]   # expand.grid: lambda fastest
         rows = np.zeros((len(grid), 4))
         csv = os.path.join(out_dir, f"insider_R{latent_rank}_reg_tuning_result.csv") if out_dir is not None else None
-        for g, (l_r, a_r) in enumerate(grid):                                                            # :147-150
+        # the fresh inits of grid point g + 1 are drawn (same generator, same order: R/insider.R:152-161) on a helper
+        # thread while the GPU fits point g: numpy's generator and the ctypes call both release the GIL
+        from concurrent.futures import ThreadPoolExecutor
+
+        def _draw():
             t_0 = _time.perf_counter()
-            cfd, col = _fresh_inits(obj, latent_rank, rng)
-            t_1 = _time.perf_counter()
-            if g % world != rank:
-                continue
-            print(f"parameter grid: {l_r},{a_r} ---------------------------------")
-            fitted = ds.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
-                                 prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
-                                 inc_continuous=obj["inc_continuous"])
-            if timings is not None:
-                timings.append(dict(lambda_=l_r, alpha=a_r, init_s=t_1 - t_0, optimize_s=_time.perf_counter() - t_1,
-                                    library_ms=ds.profile()["wall_ms"]))
-            rows[g] = (l_r, a_r, fitted["train_rmse"], fitted["test_rmse"])
-            if csv and world == 1:
-                np.savetxt(csv, rows[: g + 1], delimiter=",")
+            v = _fresh_inits(obj, latent_rank, rng)
+            return v, _time.perf_counter() - t_0
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(_draw)
+            for g, (l_r, a_r) in enumerate(grid):                                                        # :147-150
+                t_w = _time.perf_counter()
+                (cfd, col), t_draw = nxt.result()
+                t_wait = _time.perf_counter() - t_w
+                if g + 1 < len(grid):
+                    nxt = pool.submit(_draw)
+                if g % world != rank:
+                    continue
+                t_1 = _time.perf_counter()
+                print(f"parameter grid: {l_r},{a_r} ---------------------------------")
+                fitted = ds.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
+                                     prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
+                                     inc_continuous=obj["inc_continuous"])
+                if timings is not None:
+                    timings.append(dict(lambda_=l_r, alpha=a_r, init_s=t_draw, init_wait_s=t_wait,
+                                        optimize_s=_time.perf_counter() - t_1, library_ms=ds.profile()["wall_ms"]))
+                rows[g] = (l_r, a_r, fitted["train_rmse"], fitted["test_rmse"])
+                if csv and world == 1:
+                    np.savetxt(csv, rows[: g + 1], delimiter=",")
         reg_tuning = _grid_sum(rows, world)
         if csv and world > 1 and rank == 0:
             np.savetxt(csv, reg_tuning, delimiter=",")

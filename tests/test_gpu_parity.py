@@ -522,6 +522,9 @@ def test_allreduce_callback_plumbing_single_gpu(oracle):
         assert ar.calls == [6] + (per_iter * 1 + [6]) + per_iter * 9 + per_iter + [6]
         assert ar.zero_copy in (True, False)
         print("all-reduce zero-copy aliasing:", ar.zero_copy)
+        # the result-table exchange of a grid-parallel tune() on the nccl backend (host table -> device -> all-reduce -> host)
+        tab = np.arange(12.0).reshape(3, 4)
+        assert np.array_equal(api._grid_sum(tab.copy(), world=2), tab)
     finally:
         dist.destroy_process_group()
 

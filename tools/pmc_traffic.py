@@ -26,15 +26,18 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def means(d, counter):
+def series(d, counter):
     agg = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
+        rows = sorted((r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter), key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("insider::", "")
             agg[k].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+    return agg
+
+
+def means(d, counter):
+    return {k: (sum(v) / len(v), len(v)) for k, v in series(d, counter).items()}
 
 
 def main():
@@ -53,8 +56,19 @@ def main():
     stats = total(lambda k: k.startswith(("k_col_paircnt", "k_col_factored")))
     if stats == 0:      # list path: the column side is the launch with p units; both sides share the kernel name
         stats = total(lambda k: k.startswith("k_list_stats")) / 2
+    # the sweep kernel: a column solve is ONE launch from outer iteration 3 on (all genes: statistics records in, factors
+    # out) and a chain of passes in the cold outer iterations 0-2 (the passes re-read the records of the genes still running
+    # and save / restore 3 KP doubles per gene): the single-launch figure is the LAST launch of the run (outer iteration 3 of
+    # the 4-step command), the largest launch and the mean over all launches are kept beside it
+    fs, ws = series(fdir, "FETCH_SIZE"), series(wdir, "WRITE_SIZE")
+    cdk = [k for k in fs if k.startswith("k_cd_cols")]
+    cd_launch = []
+    for k in cdk:
+        cd_launch += [1024.0 * (2.0 * f + w) for f, w in zip(fs[k], ws.get(k, [0.0] * len(fs[k])))]
     ent = {"col_stats_bytes_per_launch": stats + total(lambda k: k.startswith("k_mm_rows<") and "false" in k) / 2,
-           "cd_bytes_per_launch": total(lambda k: k.startswith("k_cd_cols")),
+           "cd_bytes_per_launch": cd_launch[-1] if cd_launch else 0.0,
+           "cd_bytes_largest_pass": max(cd_launch) if cd_launch else 0.0,
+           "cd_bytes_mean_over_launches": sum(cd_launch) / len(cd_launch) if cd_launch else 0.0,
            "per_kernel": {k: v for k, v in per_kernel.items() if v["bytes_per_launch"] > 1e6}}
     path = os.path.join(ROOT, "profiles", "traffic.json")
     tj = json.load(open(path)) if os.path.exists(path) else {}
