@@ -112,3 +112,24 @@ def test_cli_round_trip_matches_oracle(tmp_path, oracle, carrier):
     R = sum(A[i][w.levels[:, i] - 1, :] for i in range(w.levels.shape[1]))
     coeff, pval = posthoc.glm_interaction(w.X - R @ Cg, w.M_train, w.levels[:, 1], Cg)
     assert coeff.shape == (int(w.n_levels[1]), w.K) and np.all((pval >= 0) & (pval <= 1))
+
+
+@pytest.mark.gpu
+def test_cli_tune_writes_the_grid_tables(tmp_path):
+    """`--tune`: insider() + tune() of R/insider.R:18-176 from files: the rank sweep at (lambda, alpha) = (0.1, 0) picks the
+    rank with the smallest test RMSE (:136), then the lambda x alpha grid (lambda fastest, :145-147) is fitted at that rank."""
+    w = workloads.small(n=60, p=48, K=4)
+    np.save(str(tmp_path / "X.npy"), w.X)
+    np.save(str(tmp_path / "L.npy"), w.levels)
+    out = str(tmp_path / "tune")
+    cmd = [sys.executable, "-m", "insider_amd.fit", "--x", str(tmp_path / "X.npy"), "--levels", str(tmp_path / "L.npy"), "--tune",
+           "--ranks", "2", "4", "--lambdas", "1", "3", "--alphas", "0.2", "0.5", "--tuning-iter", "6", "--seed", "5", "--out", out]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(os.path.join(out, "tune.json")))
+    rank_tab, reg_tab = np.array(res["rank_tuning"]), np.array(res["reg_tuning"])
+    assert rank_tab.shape == (2, 3) and list(rank_tab[:, 0]) == [2, 4]
+    assert res["latent_rank"] == int(rank_tab[np.argmin(rank_tab[:, 2]), 0])
+    assert reg_tab.shape == (4, 4)
+    assert [tuple(v) for v in reg_tab[:, :2]] == [(1.0, 0.2), (3.0, 0.2), (1.0, 0.5), (3.0, 0.5)]      # expand.grid order
+    assert np.all(np.isfinite(reg_tab[:, 2:])) and np.all(reg_tab[:, 2:] > 0)
