@@ -253,9 +253,8 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
                 for (int bb = 0; bb < NB; ++bb) b.av[s][bb] = At[(size_t)lc * KP + 16 * bb];
             }
         };
-        for (int l0 = 0; l0 < Lo; l0 += 16) {
-            PairBlk<NB> cur;
-            fetch(l0, cur);
+        // one block of 16 levels from its fetched operands
+        auto compute = [&](int l0, PairBlk<NB> &cur) {
             double hn[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {            // levels beyond the last: zero weight
@@ -290,6 +289,17 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
                         for (int bj = 0; bj < NB; ++bj)
                             acc[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.av[s][bi], P[bj][s], acc[bi][bj], 0, 0, 0);
                 }
+        };
+        // two operand sets: the loads of the next block of 16 levels are in flight during the MFMAs of the current one
+        PairBlk<NB> b0, b1;
+        fetch(0, b0);
+        for (int l0 = 0; l0 < Lo; l0 += 32) {
+            if (l0 + 16 < Lo) fetch(l0 + 16, b1);
+            compute(l0, b0);
+            if (l0 + 16 < Lo) {
+                if (l0 + 32 < Lo) fetch(l0 + 32, b0);
+                compute(l0 + 16, b1);
+            }
         }
     }
     cf_store<NB>(acc, tr, a, j, lane, rtr, qh, ss);
