@@ -338,6 +338,7 @@ def main():
         tr_stats = traffic.get("col_stats_bytes_per_launch")
         tr_cd = traffic.get("cd_bytes_per_launch")
         tr_col = (tr_stats + tr_cd) if (tr_stats is not None and tr_cd is not None) else None
+        st_cd, st_col = ds.info("cd_ms_steady"), (ds.info("col_stats_ms_steady") if tuning == 1 else 0.0)
         cd_updates = prof["sweeps"] * K
         out = {
             "metric": f"outer-iterations/sec (masked INSIDER fit, {n} x {p_total}, K={K})",
@@ -364,6 +365,11 @@ def main():
                 "algorithmic_bytes_per_launch": b_col, "avg_launch_ms": col_ms,
                 "avg_launch_ms_parts": {"statistics": gram_ms, "sweeps": cd_ms}, "launches": prof["cd_launches"],
                 "measured_copy_GBs": copy_bandwidth() if world == 1 else None,
+                # the same fraction without the cold start (outer iterations >= 5 of the timed call; the first iterations
+                # of every call run thousands of sweeps per gene from the N(0, 1e-6) inits)
+                "steady_state": ({"avg_launch_ms_parts": {"statistics": st_col, "sweeps": st_cd},
+                                  "achieved": b_col / ((st_col + st_cd) * 1e-3) / 1e9,
+                                  "frac": b_col / ((st_col + st_cd) * 1e-3) / 1e9 / HBM_PEAK_GBS} if st_cd > 0 else None),
                 "note": ("achieved = SURVEY 8d's B_col (8np X + np mask + 8nK R + 16Kp C in/out) / (statistics + sweep kernel time), "
                          "HIP events on the library's stream over the timed call.  The time is dominated by the sweep kernel "
                          "(a sequential K-step recurrence per gene and sweep, hundreds to thousands of sweeps per gene in the "

@@ -232,7 +232,9 @@ int insider_hip_get_profile(insider_hip_handle *h, double *out12);
 /* Facts about the handle that measurement code needs (bench.py's roofline): "col_stats_path" (0 = per-entry lists, 1 =
  * look-up form, 2 = pair-count form, as the cost model / options chose for the current K), "col_mfma_per_gene"
  * (v_mfma_f64_16x16x4 instructions the column-side statistics kernel issues per gene), "row_merged", "col_entries",
- * "row_entries" (padded held-out list lengths), "lists_bytes", "pair_count_bytes_per_gene", "stat_doubles", "kp". */
+ * "row_entries" (padded held-out list lengths), "lists_bytes", "pair_count_bytes_per_gene", "stat_doubles", "kp",
+ * "cd_ms_steady" / "col_stats_ms_steady" (option "profile": mean HIP-event time per outer iteration from iteration 5 on of
+ * the last optimize(), i.e. without the cold start). */
 int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out);
 
 /* Diagnostics: copy an internal per-gene array to the host: "cd_pass_slot" (uint32 x p: what the last limited pass of a

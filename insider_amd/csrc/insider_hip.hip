@@ -191,6 +191,7 @@ struct insider_hip_handle {
     // profile of the last optimize()
     std::vector<hipEvent_t> ev_col, ev_row, ev_cd, ev_test;
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double steady_cd_ms = 0, steady_col_ms = 0;   // means over the outer iterations >= 5 of the last profiled optimize()
 };
 
 namespace {
@@ -1663,6 +1664,17 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     sum_events(h->ev_row, &h->prof[2], &h->prof[3]);
     sum_events(h->ev_cd, &h->prof[4], &h->prof[5]);
     sum_events(h->ev_test, &h->prof[6], &h->prof[7]);
+    auto tail_mean = [&](std::vector<hipEvent_t> &ev) {   // one event pair per outer iteration: the mean from iteration 5 on
+        double ms = 0.0;
+        int cnt = 0;
+        for (size_t i = 10; i + 1 < ev.size(); i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) { ms += t; ++cnt; }
+        }
+        return cnt ? ms / cnt : 0.0;
+    };
+    h->steady_cd_ms = tail_mean(h->ev_cd);
+    h->steady_col_ms = tail_mean(h->ev_col);
     h->prof[8] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     h->prof[9] = (double)std::min<uint64_t>((uint64_t)iter + 1, (uint64_t)max_iter + 1);
     h->prof[10] = (double)sweeps_total;
@@ -2001,6 +2013,8 @@ int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out)
     else if (s == "kp") *out = h->KP;
     else if (s == "pair_count_bytes_per_gene") *out = h->cf_pair_ok ? h->cf.cnt_stride : 0.0;
     else if (s == "lists_bytes") *out = 12.0 * ((double)h->col_entries + (double)h->row_entries);
+    else if (s == "cd_ms_steady") *out = h->steady_cd_ms;           // option "profile": mean over outer iterations >= 5 of the last call
+    else if (s == "col_stats_ms_steady") *out = h->steady_col_ms;
     else if (s == "col_mfma_per_gene") {
         // v_mfma_f64_16x16x4_f64 instructions the column-side statistics kernel issues per gene (2048 flops each)
         if (!NB) return fail(INSIDER_ERR_ARG, "no workspace yet: run an update first");
