@@ -181,4 +181,8 @@ def test_c5_full_size_properties():
 def test_c4_full_size_properties():
     """BASELINE config 4 at full size on ONE GPU: 10000 x 200000, K = 30 (16 GB of X; the multi-GPU configuration's
     whole problem as a single slab)."""
+    import psutil
+    free = psutil.virtual_memory().available
+    if free < 40e9:      # X (16 GB) + two masks + the generator's blocks + the residual check: do not drive a small host out of memory
+        pytest.skip(f"needs ~40 GB of free host memory, {free / 1e9:.0f} GB available")
     _full_size_properties("c4", 11, compare_lists=False)
