@@ -111,3 +111,60 @@ def test_workload_configs():
     slab = workloads.make(n=50, p=3000, level_counts=(5, 2), K=3, f=0.1, gene_range=(1000, 2100))
     full = workloads.make(n=50, p=3000, level_counts=(5, 2), K=3, f=0.1)
     assert np.array_equal(slab.X, full.X[:, 1000:2100]) and np.array_equal(slab.M_train, full.M_train[:, 1000:2100])
+
+
+def test_sweep_loops_are_free_of_scratch_traffic(tmp_path, lib):
+    """The register-resident sweep kernels (insider_cd_reg.hpp) are sized so that nothing is spilled INSIDE the sweep loop:
+    a reload per sweep costs about as much as the sweep.  (The one build that also computed wrong iterates, KMAX = 22 under
+    the 128-VGPR budget in round 2, had such a reload at its loop head; parity tests caught it, this is the cheap canary.)
+    Disassembles the shipped code object and checks the sweep loop of every instantiation up to KMAX = 30 (K <= 30 covers the
+    BASELINE configurations); KMAX = 32 is known to reload one Gram element per sweep at the 168-VGPR budget."""
+    import re as _re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = str(tmp_path / "libinsider_hip.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", so], cwd=str(tmp_path), check=True, capture_output=True)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert co, "no gfx950 code object in the library"
+    dis = subprocess.run([objdump, "-d", str(tmp_path / co[0])], check=True, capture_output=True, text=True).stdout
+    # label -> address (kernels and the local labels of the sweep assembly, which split a kernel's listing)
+    labels = {m.group(2): int(m.group(1), 16) for m in _re.finditer(r"^([0-9a-f]{16}) <([^>]+)>:", dis, _re.M)}
+    funcs = _re.split(r"\n(?=[0-9a-f]{16} <_Z)", dis)
+    loops = 0
+    for fn in funcs:
+        head = fn.split("\n", 1)[0]
+        if "k_cd_cols_reg" not in head and "k_cd_batch_reg" not in head:
+            continue
+        ins = []                                   # (address, instruction, rest of the line: branch targets live there)
+        for line in fn.split("\n")[1:]:
+            m = _re.search(r"^\s*(\S.*?)\s*//\s*([0-9A-Fa-f]+):(.*)$", line)
+            if m:
+                ins.append((int(m.group(2), 16), m.group(1), m.group(3)))
+        sites = [i for i, (_, t, _r) in enumerate(ins) if t.startswith("s_load_dwordx16 s[64:79]")]
+        assert len(sites) == 1, (head, len(sites))
+        a0 = ins[sites[0]][0]
+        # the loop's back edge: the first branch after the sweep whose target lies at or shortly before the sweep's first load
+        back = None
+        for i in range(sites[0] + 1, len(ins)):
+            addr, t, rest = ins[i]
+            m = _re.search(r"<([^>+]+)(?:\+0x([0-9a-f]+))?>", rest) if _re.match(r"s_c?branch", t) else None
+            if m and m.group(1) in labels:
+                target = labels[m.group(1)] + int(m.group(2) or "0", 16)
+                if target <= a0 and a0 - target < 256:
+                    back = (i, target)
+                    break
+        assert back is not None, head
+        body = [t for addr, t, _r in ins[: back[0] + 1] if addr >= back[1]]
+        assert len(body) > 100, (head, len(body))                     # the whole sweep (code blocks + loss bookkeeping) is in it
+        spills = [t for t in body if t.startswith(("scratch_", "buffer_load", "buffer_store"))]
+        kmax = int(_re.search(r"ILi[12]ELi(\d+)E", head).group(1))
+        if kmax <= 30:
+            assert not spills, (head, spills[:4])
+        else:
+            assert all(t.startswith("scratch_load") for t in spills) and len(spills) <= 2, (head, spills[:4])
+        loops += 1
+    assert loops == 18, loops                      # 9 register budgets x {column update, stand-alone batch solver}
