@@ -394,7 +394,8 @@ int launch_build_R(insider_hip_handle *h)
 
 // R, R'R and Qfull from the current row factors (src/optimize.cpp:365-369 and the Xty of :222,235 via level sums)
 // use_side: Qfull, which only the column solve reads, is formed on the side stream next to R'R and the column statistics
-int phase_R(insider_hip_handle *h, bool use_side = false)
+// r_is_current: the row updates have just rebuilt R (every row_update() ends with k_build_R): do not build it again
+int phase_R(insider_hip_handle *h, bool use_side = false, bool r_is_current = false)
 {
     if (use_side) {
         HIPCHECK(hipEventRecord(h->ev_a_ready, h->stream));
@@ -404,7 +405,7 @@ int phase_R(insider_hip_handle *h, bool use_side = false)
         HIPCHECK(hipEventRecord(h->ev_qfull, h->side));
         h->qfull_pending = true;
     }
-    int rc = launch_build_R(h);
+    int rc = r_is_current ? INSIDER_OK : launch_build_R(h);
     if (rc) return rc;
     rc = launch_gram(h, h->R, h->n, h->RtR);
     if (rc) return rc;
@@ -1596,7 +1597,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
             for (int j = 0; j < h->m; ++j)
                 if ((rc = row_update(h, 0, j, masked, lambda1))) return rc;                     // :340-351
         // ---- column step (:365-378) -------------------------------------------------------------------------------
-        if ((rc = phase_R(h, true))) return rc;
+        if ((rc = phase_R(h, true, true))) return rc;
         const int checkpoint = iter % 10 == 0;
         if (alpha != 0.0 && iter == 0)   // later iterations: prepared on the side stream right after the previous solve
             if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
