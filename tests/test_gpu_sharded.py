@@ -132,3 +132,33 @@ def test_two_ranks_on_two_gpus_rccl(mode):
     C = np.concatenate([out[0]["C"], out[1]["C"]], axis=1)
     assert np.linalg.norm(C - single["C"]) / np.linalg.norm(single["C"]) < 1e-9
     np.testing.assert_allclose(out[0]["traj"][:, 1:8], single["traj"][:, 1:8], rtol=1e-10)
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's N > 1 path end to end (torchrun, gene sharding, max-over-ranks timing, rank 0's JSON line) with two ranks
+    time-sharing the one GPU (INSIDER_BENCH_ONE_GPU=1: host-staged all-reduce; the timing is then not a scaling figure).
+    The sharded problem's loss must equal the single-process run's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    common = ["--workload", "c2", "--steps", "6", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, INSIDER_BENCH_ONE_GPU="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", *common],
+                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], cwd=root, capture_output=True, text=True,
+                        timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["steps"] == 6 and two["config"]["genes_per_gpu"] == 10000
+    assert "2000 x 20000" in two["metric"] and two["unit"] == "outer-iterations/s" and two["value"] > 0
+    assert two["loss"] == pytest.approx(one["loss"], rel=1e-10) and two["test_rmse"] == pytest.approx(one["test_rmse"], rel=1e-10)
+    for key in ("roofline", "masked_gram", "cd_kernel"):
+        assert key in two and two["roofline"]["frac"] <= 1.0
