@@ -190,15 +190,33 @@ def grid_bench(ds, w, K, steps):
                      "that was not hidden; X / masks / lists stay resident")}
 
 
+def self_launch(n_gpus):
+    """Run this script under torch.distributed.run with one rank per GPU, as a child process (nothing in this process has
+    initialised the GPU: only argparse / numpy were imported).  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torchrun --nproc-per-node {args.gpus}", file=sys.stderr)
-            sys.exit(2)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # plain `python bench.py --gpus N`: start the N ranks as CHILD processes (one per GPU, torch.distributed.run)
+            # before this process has touched the GPU, relay their output and exit with their code
+            sys.exit(self_launch(args.gpus))
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
     # rehearsal of the N > 1 path on a one-GPU box: every rank on GPU 0, all-reduces staged through the host over gloo
@@ -400,7 +418,11 @@ def main():
                           # how-close-to-this-design's-ceiling figure, not a hardware roofline
                           "valu_issue_model_updates_per_s": 1024 * 4 * 2.4e9 / (7 * 4),
                           "valu_issue_model_frac": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * 2.4e9 / (7 * 4)),
-                          "share_of_wall": prof["cd_ms"] / (dt * 1e3)},
+                          "share_of_wall": prof["cd_ms"] / (dt * 1e3),
+                          # the reference's sweep loop has no cap (src/coordinate_descent.cpp:86-114): solves this call ended
+                          # at the library's max_sweeps without convergence (must be 0), and the longest solve
+                          "cap_hits": int(ds.info("cap_hits")), "max_gene_sweeps": int(ds.info("max_gene_sweeps")),
+                          "max_sweeps": int(ds.info("max_sweeps"))},
             "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"], "options": args.opt,
             "setup_s": {"generate": t_gen, "upload_and_precompute": t_up},
         }

@@ -188,7 +188,7 @@ template <int SLOTS, int KMAX>
 __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, const double (&q)[SLOTS],
                                       const double (&Gll)[SLOTS], double (&beta)[SLOTS], bool gene_ok, const CdParams &P,
                                       int lane, double *stash, bool resume, double (&hs)[SLOTS], double (&is)[SLOTS],
-                                      bool &unfinished, int &key)
+                                      bool &unfinished, int &key, bool &capped)
 {
     const int row = lane >> 4, i = lane & 15;
     // the scalars the sweep loop needs, copied out of the kernel-argument tuple: the sweep's assembly clobbers s63-s99,
@@ -206,6 +206,7 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
     s_acc[0] = 0.0;
     s_acc[64] = 0.0;
     unfinished = false;
+    capped = false;
     key = 0;
     RegState<SLOTS> S;
     if (!resume) {
@@ -315,6 +316,8 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             if (wa > wb && wb > wt) est = (double)W * log(wb / wt) / log(wa / wb);
             else if (wb <= wt) est = 1.0;
             key = (int)fmin(fmax(est, 1.0), 1048576.0);
+        } else {
+            capped = true;   // the sweep cap ended the solve, not convergence (the reference loops on, :86-114)
         }
     }
 #pragma unroll
@@ -374,9 +377,9 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
             hs[u] = ld ? a.hsave[(size_t)j * KP + 16 * u + i] : 0.0;
             is[u] = ld ? a.isave[(size_t)j * KP + 16 * u + i] : 0.0;
         }
-        bool unfinished;
+        bool unfinished, capped;
         int key;
-        const int sweeps = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, gene, a.cd, lane, stash, resume, hs, is, unfinished, key);
+        const int sweeps = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, gene, a.cd, lane, stash, resume, hs, is, unfinished, key, capped);
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u)
             if (gene && 16 * u + i < K) {
@@ -393,6 +396,10 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
                 a.pass_slot[j] = ((uint32_t)b << 24) | (uint32_t)atomicAdd(&a.bucket_cnt[b], 1);
             } else {
                 if (a.pass_slot) a.pass_slot[j] = CD_PASS_DONE;
+                if (a.cap_hits) {
+                    if (capped) atomicAdd(a.cap_hits, 1);
+                    if (sweeps > a.cap_hits[1]) atomicMax(a.cap_hits + 1, sweeps);   // longest solve of the call
+                }
                 a.sweeps[j] = sweeps;
                 if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
             }
@@ -464,9 +471,9 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
         beta[u] = ok ? wstart[(size_t)b * K + c] : 0.0;
     }
     double hs[SLOTS], is[SLOTS];
-    bool unfinished;
+    bool unfinished, capped;
     int key;
-    const int sw = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, prob, cd, lane, stash, false, hs, is, unfinished, key);
+    const int sw = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, prob, cd, lane, stash, false, hs, is, unfinished, key, capped);
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u)
         if (prob && 16 * u + i < K) beta_out[(size_t)b * K + 16 * u + i] = beta[u];

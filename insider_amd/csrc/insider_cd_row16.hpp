@@ -112,7 +112,8 @@ __device__ __forceinline__ void r16_dense_mv_step(double (&acc)[SLOTS], const do
 
 // The solver.  lds: this wave's LDS block (r16_lds_doubles(K) doubles) with the four Gram blocks already loaded
 // (zero diagonal).  q, Gll, beta: COORDINATE order (slot u of lane i of row g = coordinate 16u + i of gene g);
-// beta = warm start in, solution out.  gene_ok: the row holds a gene.  Returns the row's sweep count.
+// beta = warm start in, solution out.  gene_ok: the row holds a gene.  Returns the row's sweep count (negated when the
+// sweep cap, not convergence, ended the solve).
 template <int SLOTS>
 __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SLOTS], const double (&Gll)[SLOTS],
                                         double (&beta)[SLOTS], bool gene_ok, const CdParams &P, int lane)
@@ -234,7 +235,7 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
                 if ((__ballot(anyv) & rowmask) == 0) finish = true;                       // :120-121
             }
             if (finish) {   // park the row: zero increments from now on
-                my_sweeps = sweep;
+                my_sweeps = (sweep >= P.max_sweeps && fabs(dloss) > P.tol) ? -sweep : sweep;   // negative: stopped by the cap
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {
                     bfin[u] = S.beta[u];
@@ -300,11 +301,17 @@ __global__ void __launch_bounds__(64) k_cd_cols_r16(ColArgs a)
     }
     wave_sync();
     if (a.mode == COL_CD) {                                                              // :228,246
-        const int sweeps = cd_row16<SLOTS>(r16_lds, K, q, Gll, beta, gene, a.cd, lane);
+        int sweeps = cd_row16<SLOTS>(r16_lds, K, q, Gll, beta, gene, a.cd, lane);
+        const bool capped = sweeps < 0;
+        sweeps = capped ? -sweeps : sweeps;
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u)
             if (gene && 16 * u + i < K) a.C[(size_t)j * KP + 16 * u + i] = beta[u];
         if (gene && i == 0) {
+            if (a.cap_hits) {
+                if (capped) atomicAdd(a.cap_hits, 1);
+                if (sweeps > a.cap_hits[1]) atomicMax(a.cap_hits + 1, sweeps);
+            }
             a.sweeps[j] = sweeps;
             if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
         }
@@ -385,7 +392,7 @@ k_cd_batch_r16(const double *__restrict__ XtX, const double *__restrict__ Xty, c
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u)
         if (prob && 16 * u + i < K) beta_out[(size_t)b * K + 16 * u + i] = beta[u];
-    if (prob && i == 0 && sweeps_out) sweeps_out[b] = sw;
+    if (prob && i == 0 && sweeps_out) sweeps_out[b] = sw < 0 ? -sw : sw;
 }
 
 }  // namespace insider

@@ -7,7 +7,6 @@
 // checkpoints (every 10th iteration) and around the optional cross-rank all-reduce.
 #include "insider_kernels.hpp"
 
-#include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -158,12 +157,17 @@ struct insider_hip_handle {
     int row_merged = 1;               // option: use it
     double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
     int *sweeps = nullptr, *failflag = nullptr;
-    int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sweep_key)
+    int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sched_bucket)
     unsigned long long *sweep_total = nullptr;
     uint8_t *order = nullptr;
     int order_rows = 0;
     // gene scheduling for the CD kernel: genes sorted by the sweep count of their previous solve
-    int *gene_ids = nullptr, *gene_perm = nullptr, *sweeps_sorted = nullptr;
+    int *gene_perm = nullptr;
+    // the bucket sort behind it (k_sched_bucket / k_sched_scatter): two alternating sets of bucket counters, per gene its bucket
+    // and its rank in the bucket
+    int *sched_cnt[2] = {nullptr, nullptr}, *sched_rank = nullptr;
+    uint16_t *sched_bkt = nullptr;
+    int sched_flip = 0;
     // multi-pass column solves in the cold outer iterations (CdParams::sweep_limit): saved state of the unfinished genes,
     // their estimated remaining lengths (two buffers, alternating between passes) and the order of the next pass
     double *cd_hsave = nullptr, *cd_isave = nullptr;
@@ -175,8 +179,6 @@ struct insider_hip_handle {
     static constexpr int EARLY = 3;
     int *perm_early[EARLY] = {nullptr, nullptr, nullptr};
     bool have_early[EARLY] = {false, false, false};
-    void *sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
     bool have_perm = false;
     size_t stage_count = 0;
     int gram_blocks_p = 0, gram_blocks_n = 0, sc_blocks = 0;
@@ -192,6 +194,9 @@ struct insider_hip_handle {
     std::vector<hipEvent_t> ev_col, ev_row, ev_cd, ev_test;
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double steady_cd_ms = 0, steady_col_ms = 0;   // means over the outer iterations >= 5 of the last profiled optimize()
+    // of the last optimize() / optimize_col(): genes whose elastic-net solve was ended by max_sweeps, not by convergence
+    // (the reference has no cap, src/coordinate_descent.cpp:86-114), and the longest solve in sweeps
+    int cap_hits = 0, max_gene_sweeps = 0;
 };
 
 namespace {
@@ -212,11 +217,12 @@ void free_workspace(insider_hip_handle *h)
     if (h->order) (void)hipFree(h->order);
     h->order = nullptr;
     h->order_rows = 0;
-    for (void *q : {(void *)h->gene_ids, (void *)h->gene_perm, (void *)h->sweeps_sorted, h->sort_tmp, (void *)h->cd_hsave,
+    for (void *q : {(void *)h->gene_perm, (void *)h->sched_cnt[0], (void *)h->sched_cnt[1], (void *)h->sched_rank, (void *)h->sched_bkt, (void *)h->cd_hsave,
                     (void *)h->cd_isave, (void *)h->cd_pass_slot, (void *)h->cd_pass_perm[0], (void *)h->cd_pass_perm[1],
                     (void *)h->cd_pass_cnt})
         if (q) (void)hipFree(q);
-    h->gene_ids = h->gene_perm = h->sweeps_sorted = nullptr;
+    h->gene_perm = h->sched_cnt[0] = h->sched_cnt[1] = h->sched_rank = nullptr;
+    h->sched_bkt = nullptr;
     h->cd_hsave = h->cd_isave = nullptr;
     h->cd_pass_slot = nullptr;
     h->cd_pass_perm[0] = h->cd_pass_perm[1] = h->cd_pass_cnt = nullptr;
@@ -225,8 +231,6 @@ void free_workspace(insider_hip_handle *h)
         h->perm_early[e] = nullptr;
         h->have_early[e] = false;
     }
-    h->sort_tmp = nullptr;
-    h->sort_tmp_bytes = 0;
     h->have_perm = false;
     h->sweep_total = nullptr;
     h->sweeps = nullptr;
@@ -286,11 +290,14 @@ int ensure_workspace(insider_hip_handle *h, int K)
     h->stage_count = (size_t)std::max<int64_t>(std::max<int64_t>(h->p, h->n), h->SL) * KP;
     if ((rc = dmalloc(&h->stage, h->stage_count))) return rc;
     if ((rc = dmalloc(&h->sweeps, (size_t)h->p))) return rc;
-    if ((rc = dmalloc(&h->failflag, 2))) return rc;   // [0] a system was singular, [1] ridge genes wait for the general route
+    // [0] a system was singular, [1] ridge genes wait for the general route, [2] genes stopped by max_sweeps, [3] longest solve
+    if ((rc = dmalloc(&h->failflag, 4))) return rc;
     if ((rc = dmalloc(&h->sweep_total, 256))) return rc;
-    if ((rc = dmalloc(&h->gene_ids, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
-    if ((rc = dmalloc(&h->sweeps_sorted, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->sched_cnt[0], (size_t)SCHED_BUCKETS))) return rc;
+    if ((rc = dmalloc(&h->sched_cnt[1], (size_t)SCHED_BUCKETS))) return rc;
+    if ((rc = dmalloc(&h->sched_rank, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->sched_bkt, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sweep_key, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->cd_hsave, (size_t)h->p * KP))) return rc;
     if ((rc = dmalloc(&h->cd_isave, (size_t)h->p * KP))) return rc;
@@ -300,22 +307,15 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->cd_pass_cnt, (size_t)CD_BUCKETS + 2))) return rc;
     for (int e = 0; e < insider_hip_handle::EARLY; ++e)
         if ((rc = dmalloc(&h->perm_early[e], (size_t)h->p))) return rc;
-    {
-        std::vector<int> ids(h->p);
-        for (int64_t i = 0; i < h->p; ++i) ids[i] = (int)i;
-        HIPCHECK(hipMemcpy(h->gene_ids, ids.data(), (size_t)h->p * sizeof(int), hipMemcpyHostToDevice));
-        size_t bytes = 0;
-        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, h->sweeps, h->sweeps_sorted, h->gene_ids,
-                                                              h->gene_perm, (int)h->p, 0, 32, h->stream));
-        HIPCHECK(hipMalloc(&h->sort_tmp, bytes ? bytes : 1));
-        h->sort_tmp_bytes = bytes;
-    }
+    HIPCHECK(hipMemsetAsync(h->sched_cnt[0], 0, SCHED_BUCKETS * sizeof(int), h->stream));
+    HIPCHECK(hipMemsetAsync(h->sched_cnt[1], 0, SCHED_BUCKETS * sizeof(int), h->stream));
+    h->sched_flip = 0;
     h->have_perm = false;
     // rows of the padded factor buffers beyond K must stay zero: C rows are gathered with pitch KP and the
     // pad genes of the transposed layout index rows p..ldp-1
     HIPCHECK(hipMemsetAsync(h->C, 0, (size_t)std::max<int64_t>(h->p, h->ldp) * KP * sizeof(double), h->stream));
     HIPCHECK(hipMemsetAsync(h->R, 0, (size_t)h->n * KP * sizeof(double), h->stream));
-    HIPCHECK(hipMemsetAsync(h->failflag, 0, 2 * sizeof(int), h->stream));
+    HIPCHECK(hipMemsetAsync(h->failflag, 0, 4 * sizeof(int), h->stream));
     h->K = K;
     return INSIDER_OK;
 }
@@ -446,6 +446,21 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     }
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)max_sweeps * 64, 256)), dim3(256), 0, stream, seed, iter, K,
                        max_sweeps, order_mode, K * 8, reg_kmax(K), h->order);
+    KCHECK();
+    return INSIDER_OK;
+}
+
+// the launch order of the next column solve: genes by decreasing key, a bucket sort on a log scale (insider_kernels.hpp).
+// sweeps != null: the keys are first updated from the last solve's sweep counts (reset: replaced, else smoothed)
+int launch_gene_order(insider_hip_handle *h, const int *sweeps, int reset, int float_bits, hipStream_t st)
+{
+    int *cnt = h->sched_cnt[h->sched_flip], *cnt_next = h->sched_cnt[h->sched_flip ^ 1];
+    h->sched_flip ^= 1;
+    hipLaunchKernelGGL(k_sched_bucket, dim3(cdiv(h->p, 256)), dim3(256), 0, st, sweeps, (int)h->p, reset, float_bits,
+                       h->sweep_key, cnt, h->sched_bkt, h->sched_rank);
+    KCHECK();
+    hipLaunchKernelGGL(k_sched_scatter, dim3(cdiv(h->p, 256)), dim3(256), 0, st, (const int *)cnt, cnt_next,
+                       (const uint16_t *)h->sched_bkt, (const int *)h->sched_rank, (int)h->p, h->gene_perm);
     KCHECK();
     return INSIDER_OK;
 }
@@ -610,6 +625,7 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.pass_count = nullptr;
         a.pass_slot = nullptr;
         a.bucket_cnt = nullptr;
+        a.cap_hits = solve ? h->failflag + 2 : nullptr;
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
         if (h->cd_variant == 0 && h->K <= 32) {
             // Cold outer iterations: thousands of sweeps per gene whose counts no history predicts, so a wave's four genes
@@ -661,12 +677,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
             HIPCHECK(hipStreamWaitEvent(h->side, h->ev_cd_done, 0));
             st = h->side;
         }
-        size_t bytes = h->sort_tmp_bytes;
-        hipLaunchKernelGGL(k_sweep_key, dim3(cdiv(h->p, 256)), dim3(256), 0, st, (const int *)h->sweeps, (int)h->p,
-                           (outer_iter < insider_hip_handle::EARLY || !h->have_perm) ? 1 : 0, h->sweep_key);
-        KCHECK();
-        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweep_key, h->sweeps_sorted,
-                                                              h->gene_ids, h->gene_perm, (int)h->p, 0, 32, st));
+        if ((rc = launch_gene_order(h, h->sweeps, (outer_iter < insider_hip_handle::EARLY || !h->have_perm) ? 1 : 0, 0, st)))
+            return rc;
         h->have_perm = true;
         if (early) {
             HIPCHECK(hipMemcpyAsync(h->perm_early[outer_iter], h->gene_perm, (size_t)h->p * sizeof(int),
@@ -940,6 +952,17 @@ int check_fail_flag(insider_hip_handle *h)
         HIPCHECK(hipMemsetAsync(h->failflag, 0, sizeof(int), h->stream));
         return fail(INSIDER_ERR_SOLVE, "a ridge normal-equation system was not positive definite");
     }
+    return INSIDER_OK;
+}
+
+// cap-hit counter and longest solve of the column updates since the last reset (failflag[2..3])
+int read_cap_hits(insider_hip_handle *h)
+{
+    int v[2] = {0, 0};
+    HIPCHECK(hipMemcpyAsync(v, h->failflag + 2, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    h->cap_hits = v[0];
+    h->max_gene_sweeps = v[1];
     return INSIDER_OK;
 }
 
@@ -1571,13 +1594,12 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     uint32_t iter = 0;
     unsigned long long sweeps_total = 0;
     HIPCHECK(hipMemsetAsync(h->sweep_total, 0, 256 * sizeof(unsigned long long), h->stream));
+    HIPCHECK(hipMemsetAsync(h->failflag + 2, 0, 2 * sizeof(int), h->stream));
     if (alpha != 0.0 && !h->have_perm && !h->have_early[0]) {   // no history on this handle: order the genes by sum of squares
-        size_t bytes = h->sort_tmp_bytes;
         hipLaunchKernelGGL(k_yy_key, dim3(cdiv(h->p, 256)), dim3(256), 0, h->stream,
                            (const double *)(masked ? h->yy_train : h->yy_all), (int)h->p, h->sweep_key);
         KCHECK();
-        HIPCHECK(hipcub::DeviceRadixSort::SortPairsDescending(h->sort_tmp, bytes, h->sweep_key, h->sweeps_sorted,
-                                                              h->gene_ids, h->gene_perm, (int)h->p, 0, 32, h->stream));
+        if ((rc = launch_gene_order(h, nullptr, 0, 1, h->stream))) return rc;
         h->have_perm = true;
     }
     while (iter <= max_iter) {                                                                  // :325
@@ -1638,6 +1660,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     }
     if ((rc = download_factors(h, A, C, K))) return rc;
     if ((rc = check_fail_flag(h))) return rc;
+    if ((rc = read_cap_hits(h))) return rc;
     HIPCHECK(hipStreamSynchronize(h->side2));
     HIPCHECK(hipStreamSynchronize(h->side3));
     HIPCHECK(hipStreamSynchronize(h->side));   // the gene orders kept for the next call
@@ -1701,7 +1724,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         (void)hipStreamSynchronize(h->side2);
         (void)hipStreamSynchronize(h->side3);
         h->side_pending = h->qfull_pending = h->w_ready = false;
-        if (h->failflag) (void)hipMemset(h->failflag, 0, 2 * sizeof(int));
+        if (h->failflag) (void)hipMemset(h->failflag, 0, 4 * sizeof(int));
         clear_events(h);
         g_err = keep;
     }
@@ -1787,8 +1810,10 @@ int insider_hip_optimize_col(insider_hip_handle *h, double *const *A, double *C,
     if (alpha != 0.0)
         if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
     if (tuning == 1) if ((rc = launch_col_stats(h, false))) return rc;
+    HIPCHECK(hipMemsetAsync(h->failflag + 2, 0, 2 * sizeof(int), h->stream));
     if ((rc = launch_col_solve(h, tuning, true, lambda, alpha, tol, 0, false))) return rc;
     if ((rc = download_factors(h, nullptr, C, K))) return rc;
+    if ((rc = read_cap_hits(h))) return rc;
     return check_fail_flag(h);
 }
 
@@ -2014,6 +2039,9 @@ int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out)
     else if (s == "kp") *out = h->KP;
     else if (s == "pair_count_bytes_per_gene") *out = h->cf_pair_ok ? h->cf.cnt_stride : 0.0;
     else if (s == "lists_bytes") *out = 12.0 * ((double)h->col_entries + (double)h->row_entries);
+    else if (s == "cap_hits") *out = h->cap_hits;                   // last optimize() / optimize_col(): solves ended by max_sweeps
+    else if (s == "max_gene_sweeps") *out = h->max_gene_sweeps;     // ... and the longest solve, in sweeps
+    else if (s == "max_sweeps") *out = h->max_sweeps;
     else if (s == "cd_ms_steady") *out = h->steady_cd_ms;           // option "profile": mean over outer iterations >= 5 of the last call
     else if (s == "col_stats_ms_steady") *out = h->steady_col_ms;
     else if (s == "col_mfma_per_gene") {

@@ -268,7 +268,7 @@ __device__ __forceinline__ double group_max(double v)
 // Goff: this group's LDS block, K rows of pitch W: Goff[k * W + l] = XtX[k][l] with a ZERO diagonal; Gll = XtX[l][l].
 // q = Xty_l; beta: warm start in / solution out; g_out = (Xty - XtX beta)_l at the solution.
 // valid: lane owns a real coordinate of a real gene.  s_ord: per-wave LDS scratch of 64 ints.
-// Returns this group's sweep count.
+// Returns this group's sweep count, negated when the sweep cap (not convergence) ended the solve.
 template <int W>
 __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, double Gll, double q, double &beta,
                                          double &g_out, bool valid, const CdParams &P, int lane)
@@ -337,7 +337,7 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
                 }
             }
             if (finish) {   // park the group: zero increments from now on
-                my_sweeps = sweep;
+                my_sweeps = (sweep >= P.max_sweeps && fabs(dloss) > P.tol) ? -sweep : sweep;   // negative: stopped by the cap
                 bfinal = beta;
                 gfinal = g1;
                 beta = 0.0;
@@ -662,6 +662,9 @@ struct ColArgs {
     uint32_t *pass_slot;         // limited pass, per gene it processed: CD_PASS_DONE, or (bucket << 24 | rank in the bucket) of a gene it
                                  // leaves unfinished (bucket = its estimated remaining sweeps on a log scale, see k_pass_scatter)
     int *bucket_cnt;             // limited pass: CD_BUCKETS counters (zeroed by the host)
+    int *cap_hits;               // [0] counter of the genes a solve stopped at max_sweeps without convergence (the reference has no
+                                 // cap, src/coordinate_descent.cpp:86-114), [1] the longest solve: insider_hip_get_info("cap_hits" /
+                                 // "max_gene_sweeps"); may be null
 };
 
 constexpr int CD_BUCKETS = 192;                  // 8 per octave of the estimate (1 .. 2^20 sweeps), longest first
@@ -725,8 +728,14 @@ __global__ void __launch_bounds__(WPB * 64) k_cd_cols(ColArgs a)
     int sweeps = 0;
     if (a.mode == COL_CD) {                                                             // :228,246
         sweeps = cd_sweeps<W>(Goff, s_ord[w], K, Gll, q, beta, g, valid, a.cd, lane);
+        const bool capped = sweeps < 0;
+        sweeps = capped ? -sweeps : sweeps;
         if (valid) a.C[(size_t)j * KP + l] = beta;
         if (gene && l == 0) {
+            if (a.cap_hits) {
+                if (capped) atomicAdd(a.cap_hits, 1);
+                if (sweeps > a.cap_hits[1]) atomicMax(a.cap_hits + 1, sweeps);
+            }
             a.sweeps[j] = sweeps;
             if (a.sweep_bins) atomicAdd(&a.sweep_bins[(blockIdx.x * WPB + w) & 255], (unsigned long long)sweeps);
         }
@@ -895,7 +904,7 @@ k_cd_batch(const double *__restrict__ XtX, const double *__restrict__ Xty, const
     double beta = valid ? wstart[(size_t)b * K + l] : 0.0, g;
     const int sw = cd_sweeps<W>(Goff, s_ord[w], K, Gll, q, beta, g, valid, cd, lane);
     if (valid) beta_out[(size_t)b * K + l] = beta;
-    if (prob && l == 0 && sweeps_out) sweeps_out[b] = sw;
+    if (prob && l == 0 && sweeps_out) sweeps_out[b] = sw < 0 ? -sw : sw;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -930,21 +939,77 @@ __global__ void __launch_bounds__(256) k_cont_sums(const double *__restrict__ va
     S[(size_t)g * SLP + SLcat + j] = s;
 }
 
-// scheduling key of every gene for the next column solve: its sweep count (x 16), smoothed over the outer iterations
-// once the counts have settled (reset = the first iterations, whose counts fall by an order of magnitude each).
-// Measured at c3: packing genes four to a wave by the last count alone wastes 12-19 % (max of four > mean), by the
-// smoothed count 8-13 %.
-__global__ void __launch_bounds__(256) k_sweep_key(const int *__restrict__ sweeps, int p, int reset, int *__restrict__ key)
+// ---- gene scheduling for the sweep kernel: longest-first launch order, genes of similar length sharing a wave -----------
+// Four genes share a wave until the slowest is done, so the launch order groups genes by their expected sweep count:
+// key = the gene's sweep count (x 16) smoothed over the outer iterations once the counts have settled (reset = the first
+// iterations, whose counts fall by an order of magnitude each; measured at c3: packing by the last count alone wastes
+// 12-19 % (max of four > mean), by the smoothed count 8-13 %); for the first solve of a data set, with no counts yet, the
+// gene's sum of squares (float bits; genes that carry signal need more sweeps: 16 % waste against 37 % in natural order).
+// The order is a bucket sort on a log scale — 64 buckets per octave for the integer keys (1.1 % apart, far below the
+// noise of the prediction), 16 per octave for the float keys — with one integer atomic per gene: the order inside a
+// bucket is the order of the atomics, which decides which genes share a wave and never a result.  Two launches per
+// outer iteration (this replaces a library radix / merge sort: ~7 launches).
+constexpr int SCHED_BUCKETS = 2048;
+__device__ __forceinline__ int sched_bucket(int key, int float_bits)
+{
+    int b = float_bits ? (key >> 19) - (63 << 4)                          // float bits: 2^-64 .. 2^64, 16 per octave
+                       : (__float_as_int((float)key) >> 17) - (127 << 6);   // integer: 1 .. 2^31, 64 per octave
+    b = b < 0 ? 0 : (b > SCHED_BUCKETS - 1 ? SCHED_BUCKETS - 1 : b);
+    return SCHED_BUCKETS - 1 - b;                                          // longest first
+}
+
+// sweeps != null: key[j] = reset ? 16 sweeps[j] : (key[j] + 16 sweeps[j]) / 2 (integer keys); else key[] is given
+// (float bits when float_bits).  bkt / rank: the gene's bucket and its rank inside it; cnt: SCHED_BUCKETS counters, zero on entry.
+__global__ void __launch_bounds__(256) k_sched_bucket(const int *__restrict__ sweeps, int p, int reset, int float_bits,
+                                                      int *__restrict__ key, int *__restrict__ cnt,
+                                                      uint16_t *__restrict__ bkt, int *__restrict__ rank)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= p) return;
-    const int s16 = sweeps[j] * 16;
-    key[j] = reset ? s16 : (key[j] + s16) / 2;
+    int k = key[j];
+    if (sweeps) {
+        const int s16 = sweeps[j] * 16;
+        k = reset ? s16 : (k + s16) / 2;
+        key[j] = k;
+    }
+    const int b = sched_bucket(k, float_bits);
+    bkt[j] = (uint16_t)b;
+    rank[j] = atomicAdd(&cnt[b], 1);
 }
 
-// First column solve of a data set, no sweep counts yet: the genes' sums of squares are a usable proxy (genes that carry
-// signal need more sweeps; at c3 ordering by them leaves 16 % packing waste against 37 % in natural order).  Positive
-// floats order like their bit patterns.
+// perm[start of the gene's bucket + its rank] = gene; every block forms the bucket starts itself (exclusive scan of the
+// SCHED_BUCKETS counters in LDS).  Block 0 also clears cnt_next, the counters of the next use (two sets alternate).
+__global__ void __launch_bounds__(256) k_sched_scatter(const int *__restrict__ cnt, int *__restrict__ cnt_next,
+                                                       const uint16_t *__restrict__ bkt, const int *__restrict__ rank, int p,
+                                                       int *__restrict__ perm)
+{
+    constexpr int PER = SCHED_BUCKETS / 256;
+    __shared__ int off[SCHED_BUCKETS];
+    __shared__ int tot[256];
+    const int t = threadIdx.x;
+    int loc[PER], run = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { loc[q] = run; run += cnt[t * PER + q]; }
+    tot[t] = run;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {   // inclusive scan of the 256 thread totals
+        const int v = t >= o ? tot[t - o] : 0;
+        __syncthreads();
+        tot[t] += v;
+        __syncthreads();
+    }
+    const int base = tot[t] - run;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) off[t * PER + q] = base + loc[q];
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int q = t; q < SCHED_BUCKETS; q += 256) cnt_next[q] = 0;
+    const int j = blockIdx.x * 256 + t;
+    if (j < p) perm[off[bkt[j]] + rank[j]] = j;
+}
+
+// First column solve of a data set, no sweep counts yet: the genes' sums of squares as float bits (positive floats order
+// like their bit patterns).
 __global__ void __launch_bounds__(256) k_yy_key(const double *__restrict__ yy, int p, int *__restrict__ key)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -135,21 +135,18 @@ def test_two_ranks_on_two_gpus_rccl(mode):
 
 
 def test_bench_two_rank_rehearsal_on_one_gpu():
-    """bench.py's N > 1 path end to end (torchrun, gene sharding, max-over-ranks timing, rank 0's JSON line) with two ranks
-    time-sharing the one GPU (INSIDER_BENCH_ONE_GPU=1: host-staged all-reduce; the timing is then not a scaling figure).
-    The sharded problem's loss must equal the single-process run's."""
+    """bench.py's N > 1 path end to end from a PLAIN invocation (`python bench.py --gpus 2`: the script starts its ranks
+    itself as a torch.distributed.run child process before touching the GPU; gene sharding, max-over-ranks timing, rank
+    0's JSON line) with two ranks time-sharing the one GPU (INSIDER_BENCH_ONE_GPU=1: host-staged all-reduce; the timing is
+    then not a scaling figure).  The sharded problem's loss must equal the single-process run's."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     common = ["--workload", "c2", "--steps", "6", "--warmup", "1", "--no-cpu-baseline"]
-    env = dict(os.environ, INSIDER_BENCH_ONE_GPU="1")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                         "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", *common],
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["INSIDER_BENCH_ONE_GPU"] = "1"
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *common],
                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])

@@ -2,6 +2,7 @@
 API mirror behaves like the reference's R code, and the product fails loudly without a GPU (no CPU fallback)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -168,3 +169,28 @@ def test_sweep_loops_are_free_of_scratch_traffic(tmp_path, lib):
             assert all(t.startswith("scratch_load") for t in spills) and len(spills) <= 2, (head, spills[:4])
         loops += 1
     assert loops == 18, loops                      # 9 register budgets x {column update, stand-alone batch solver}
+
+
+def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell (no torchrun environment) must start the N ranks itself, as a child
+    process (torch.distributed.run, rendezvous on 127.0.0.1) and before anything touches the GPU."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
