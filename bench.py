@@ -151,7 +151,7 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
                      "ratio can be separated from the hardware part")}
 
 
-def grid_bench(ds, w, K, steps):
+def grid_bench(ds, w, K, steps, warm_start=False):
     """BASELINE config 3 as written: tune()'s lambda x alpha grid (README.md:79 of the reference: lambda in {1,3,..,19},
     alpha in {0.2,..,0.5}) on the resident data set, tuning_iter = steps - 1, fresh inits per point (R/insider.R:142-174)."""
     from insider_amd import api
@@ -170,12 +170,13 @@ def grid_bench(ds, w, K, steps):
     import io
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
-        res = api.tune(obj, latent_dimension=np.array([K]), lambda_=lambdas, alpha=alphas, timings=timings)
+        res = api.tune(obj, latent_dimension=np.array([K]), lambda_=lambdas, alpha=alphas, timings=timings, warm_start=warm_start)
     wall = time.perf_counter() - t0
     tab = res["reg_tuning"]
     best = tab[int(np.argmin(tab[:, 3]))]
     npts = len(timings)
     return {"points": npts, "lambda": lambdas, "alpha": alphas, "iterations_per_point": steps, "wall_s": wall,
+            "warm_start": bool(warm_start), "table": [[float(v) for v in row] for row in tab],
             "mean_outer_iterations_per_s": npts * steps / wall,
             "per_point_ms": {"init_draw": 1e3 * float(np.mean([t["init_s"] for t in timings])),
                              "init_draw_not_hidden": 1e3 * float(np.mean([t["init_wait_s"] for t in timings])),
@@ -436,6 +437,13 @@ def main():
         if args.grid and world == 1:
             try:
                 out["grid"] = grid_bench(ds, w, K, args.steps)
+                # opt-in extension (NOT the reference's behaviour): every grid point starts from its nearest finished neighbour
+                gw = grid_bench(ds, w, K, args.steps, warm_start=True)
+                cold = np.array(out["grid"].pop("table"))
+                warm = np.array(gw.pop("table"))
+                gw["max_abs_test_rmse_difference_vs_cold"] = float(np.max(np.abs(cold[:, 3] - warm[:, 3])))
+                gw["best_point_agrees_with_cold"] = bool(np.argmin(cold[:, 3]) == np.argmin(warm[:, 3]))
+                out["grid_warm_start"] = gw
             except Exception as e:
                 out["grid"] = {"failed": repr(e)}
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is an N = 1 figure

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinsider_hip.so")
+LIB_PATH = os.environ.get("INSIDER_HIP_LIB") or os.path.join(_HERE, "libinsider_hip.so")   # INSIDER_HIP_LIB: another build of the same C ABI
 
 OK, ERR_ARG, ERR_SOLVE, ERR_ALLOC, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_COMM = range(8)
 TRAJ_STRIDE = 10

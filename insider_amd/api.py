@@ -441,8 +441,26 @@ def _grid_sum(rows, world):
     return t.cpu().numpy()
 
 
-def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None, rank=0, world=1, timings=None):
+def _nearest_finished(done, g, n_lambda):
+    """Index of the finished grid point closest to g on the (alpha row, lambda column) lattice (expand.grid order: lambda
+    fastest), ties to the lower index; None when nothing is finished yet."""
+    best, bd = None, None
+    for h in done:
+        d = abs(h // n_lambda - g // n_lambda) + abs(h % n_lambda - g % n_lambda)
+        if bd is None or d < bd or (d == bd and h < best):
+            best, bd = h, d
+    return best
+
+
+def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None, rank=0, world=1, timings=None,
+         warm_start=False):
     """tune() of R/insider.R:81-176.  ``out_dir``: where to write the reference's CSVs (None = do not write).
+
+    ``warm_start`` (opt-in, NOT the reference's behaviour, which draws fresh N(0, 0.001^2) inits for every grid point,
+    R/insider.R:152-161): the fit of (lambda, alpha) grid point g starts from the fitted factors of the nearest grid point
+    this rank has already finished instead of from its fresh draw (which is still drawn, so the generator state — and
+    every point that does start cold — is unchanged).  The first outer iterations of a cold fit run thousands of
+    coordinate sweeps per gene to leave the near-zero inits; a neighbouring optimum is a few hundred sweeps away.
 
     ``rank`` / ``world``: grid-parallel tuning across the GPUs of a node: every rank keeps the
     whole data set resident, grid point g is fitted by rank g % world and the result tables are summed over
@@ -499,6 +517,7 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
             v = _fresh_inits(obj, latent_rank, rng)
             return v, _time.perf_counter() - t_0
 
+        finished = {}       # warm_start: grid index -> (row factors, column factor) of the points this rank has fitted
         with ThreadPoolExecutor(max_workers=1) as pool:
             nxt = pool.submit(_draw)
             for g, (l_r, a_r) in enumerate(grid):                                                        # :147-150
@@ -511,11 +530,19 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
                     continue
                 t_1 = _time.perf_counter()
                 print(f"parameter grid: {l_r},{a_r} ---------------------------------")
+                src = _nearest_finished(finished, g, lam.size) if warm_start else None
+                if src is not None:
+                    cfd = [a.copy(order="F") for a in finished[src][0]]
+                    col = finished[src][1].copy(order="F")
                 fitted = ds.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
                                      prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
                                      inc_continuous=obj["inc_continuous"])
+                if warm_start:
+                    finished[g] = (list(fitted["row_matrices"].values()), fitted["column_factor"])
+                    for old_g in [h for h in finished if h < g - lam.size * world - world]:   # keep about one alpha row back
+                        del finished[old_g]
                 if timings is not None:
-                    timings.append(dict(lambda_=l_r, alpha=a_r, init_s=t_draw, init_wait_s=t_wait,
+                    timings.append(dict(lambda_=l_r, alpha=a_r, init_s=t_draw, init_wait_s=t_wait, warm_from=src,
                                         optimize_s=_time.perf_counter() - t_1, library_ms=ds.profile()["wall_ms"]))
                 rows[g] = (l_r, a_r, fitted["train_rmse"], fitted["test_rmse"])
                 if csv and world == 1:

@@ -146,7 +146,10 @@ __device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][1
 }
 
 // waves per SIMD the register budget of an instantiation is sized for (512 VGPRs per SIMD lane)
-__host__ __device__ constexpr int reg_waves(int KMAX) { return KMAX <= 20 ? 4 : 3; }
+#ifndef INSIDER_REG_4WAVE_MAX
+#define INSIDER_REG_4WAVE_MAX 20   // largest KMAX built for 4 waves per SIMD (128 VGPRs)
+#endif
+__host__ __device__ constexpr int reg_waves(int KMAX) { return KMAX <= INSIDER_REG_4WAVE_MAX ? 4 : 3; }
 // smallest instantiated KMAX >= K
 __host__ __device__ constexpr int reg_kmax(int K) { return K <= 16 ? 16 : (K + 1) & ~1; }
 
@@ -169,11 +172,14 @@ __device__ __forceinline__ void reg_gemv(double (&acc)[SLOTS], const double (&v)
 // LDS doubles per wave: per lane and slot D = XtX_kk + l2, the sweep-start beta and w = beta D - h, and the solution
 // (values that are not needed inside the sweep live here so that the registers hold only the Gram columns and the
 // sweep state)
-constexpr int REG_STASH = 5 * 2 * 64;   // + two 64-entry windows of |loss change| sums (multi-pass: remaining-length estimate)
+constexpr int REG_STASH = 6 * 2 * 64;   // D, beta0, w0, solution | two 64-entry windows of |loss change| sums (multi-pass:
+                                        // remaining-length estimate) | 1 / D (for the KKT re-admission, :123: no division
+                                        // and none of its temporaries inside the sweep loop)
 
-// The solver.  G: columns 16u + i of the row's Gram matrix (zero diagonal).  q, Gll, beta: coordinate 16u + i of
-// gene `row`; beta = warm start in, solution out.  gene_ok: the row holds a gene.  stash: this wave's REG_STASH
-// doubles of LDS.  Returns the row's sweep count.
+// The solver, in two parts: cd_reg_begin (start values from q, Gll, the warm start / the saved state; no matrix) and cd_reg
+// (the sweeps).  G: columns 16u + i of the row's Gram matrix (zero diagonal).  q, Gll, beta: coordinate 16u + i of
+// gene `row`; beta = warm start in (cd_reg_begin), solution out (cd_reg).  gene_ok: the row holds a gene.  stash: this
+// wave's REG_STASH doubles of LDS.  cd_reg returns the row's sweep count.
 // Loss change of a sweep (:112-114) from per-coordinate start/end values: with g = h - beta XtX_kk (the gradient part
 // Xty - XtX beta) the exact change is sum_l [-1/2 db (g0 + g1) + 1/2 l2 (b1^2 - b0^2) + la (|b1| - |b0|)]
 // = sum_l [1/2 db (w0 + w1) + la (|b1| - |b0|)],  w = beta (XtX_kk + l2) - h;  the end values of one sweep are the
@@ -184,30 +190,18 @@ constexpr int REG_STASH = 5 * 2 * 64;   // + two 64-entry windows of |loss chang
 // iterates are bit-identical to an uninterrupted solve.  A row still running when the pass ends at P.sweep_limit returns
 // unfinished = true with its state in hs / is / beta and `key` = its estimated remaining sweeps (from the geometric decay
 // of the loss change over the last two 8-sweep windows; > 0).
-template <int SLOTS, int KMAX>
-__device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, const double (&q)[SLOTS],
-                                      const double (&Gll)[SLOTS], double (&beta)[SLOTS], bool gene_ok, const CdParams &P,
-                                      int lane, double *stash, bool resume, double (&hs)[SLOTS], double (&is)[SLOTS],
-                                      bool &unfinished, int &key, bool &capped)
+// Start values WITHOUT the Gram matrix (so that the kernels can fetch it afterwards: the start values' inputs and the
+// 2 x KMAX matrix registers are then never live together): screening, beta, 1/D, h = q (the caller's matrix product
+// follows in cd_reg), D and the provisional solution in the stash.
+template <int SLOTS>
+__device__ __forceinline__ RegState<SLOTS> cd_reg_begin(int K, const double (&q)[SLOTS], const double (&Gll)[SLOTS],
+                                                        const double (&beta)[SLOTS], bool gene_ok, const CdParams &P, int lane,
+                                                        double *stash, bool resume, const double (&hs)[SLOTS],
+                                                        const double (&is)[SLOTS])
 {
-    const int row = lane >> 4, i = lane & 15;
-    // the scalars the sweep loop needs, copied out of the kernel-argument tuple: the sweep's assembly clobbers s63-s99,
-    // and the compiler otherwise keeps the s_load_dwordx8 result there and restores it (8 v_readlane) twice per sweep
-    double la = P.la, tol = P.tol;
+    const int i = lane & 15;
     const double l2 = P.l2;
-    int max_sweeps = P.max_sweeps;
-    const uint8_t *order = P.order;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(la), "+s"(tol), "+s"(max_sweeps), "+s"(order));
-#endif
-    const uint64_t rowmask = 0xffffull << (16 * row);
-    double *s_d = stash + lane, *s_b = s_d + 128, *s_w = s_d + 256, *s_out = s_d + 384;   // [slot * 64]
-    double *s_acc = s_d + 512;                                                           // [window * 64]
-    s_acc[0] = 0.0;
-    s_acc[64] = 0.0;
-    unfinished = false;
-    capped = false;
-    key = 0;
+    double *s_d = stash + lane, *s_out = s_d + 384, *s_ri = s_d + 640;   // [slot * 64]
     RegState<SLOTS> S;
     if (!resume) {
         // ---- strong rule and start values (:74-80) -----------------------------------------------------------
@@ -219,14 +213,14 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
         for (int u = 0; u < SLOTS; ++u) {
             const bool valid = gene_ok && 16 * u + i < K;
             const bool active = valid && !(fabs(q[u]) < thr);
-            const double D = (valid ? Gll[u] : 1.0) + l2;
+            const double D = (valid ? Gll[u] : 1.0) + l2, rD = cd_rcp(D);
             S.beta[u] = active ? beta[u] : 0.0;                                           // :78
-            S.inv[u] = active ? cd_rcp(D) : 0.0;
+            S.inv[u] = active ? rD : 0.0;
             S.h[u] = valid ? q[u] : 0.0;
             s_d[64 * u] = D;
+            s_ri[64 * u] = rD;
             s_out[64 * u] = S.beta[u];
         }
-        reg_gemv<SLOTS, KMAX>(S.h, S.beta, G, K);                                         // :79 h = q - offdiag(XtX) beta
     } else {
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {   // the state a limited pass saved: no screening, no re-derivation
@@ -234,10 +228,39 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             S.beta[u] = valid ? beta[u] : 0.0;
             S.inv[u] = valid ? is[u] : 0.0;
             S.h[u] = valid ? hs[u] : 0.0;
-            s_d[64 * u] = (valid ? Gll[u] : 1.0) + l2;
+            const double D = (valid ? Gll[u] : 1.0) + l2;
+            s_d[64 * u] = D;
+            s_ri[64 * u] = cd_rcp(D);
             s_out[64 * u] = S.beta[u];
         }
     }
+    return S;
+}
+
+// S: the start values of cd_reg_begin; beta / hs / is are outputs here
+template <int SLOTS, int KMAX>
+__device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS][KMAX], int K, double (&beta)[SLOTS],
+                                      bool gene_ok, const CdParams &P, int lane, double *stash, bool resume,
+                                      double (&hs)[SLOTS], double (&is)[SLOTS], bool &unfinished, int &key, bool &capped)
+{
+    const int i = lane & 15;
+    // the scalars the sweep loop needs, copied out of the kernel-argument tuple: the sweep's assembly clobbers s63-s99,
+    // and the compiler otherwise keeps the s_load_dwordx8 result there and restores it (8 v_readlane) twice per sweep
+    double la = P.la, tol = P.tol;
+    int max_sweeps = P.max_sweeps;
+    const uint8_t *order = P.order;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(la), "+s"(tol), "+s"(max_sweeps), "+s"(order));
+#endif
+    double *s_d = stash + lane, *s_b = s_d + 128, *s_w = s_d + 256, *s_out = s_d + 384;   // [slot * 64]
+    double *s_acc = s_d + 512;                                                           // [window * 64]
+    const double *s_ri = s_d + 640;                                                      // [slot * 64]
+    s_acc[0] = 0.0;
+    s_acc[64] = 0.0;
+    unfinished = false;
+    capped = false;
+    key = 0;
+    if (!resume) reg_gemv<SLOTS, KMAX>(S.h, S.beta, G, K);                                // :79 h = q - offdiag(XtX) beta
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         s_b[64 * u] = S.beta[u];
@@ -279,13 +302,19 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
         if (sweep > win) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);                   // wave-uniform, limited passes only
         const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
         if (cand != 0) {                                                                    // wave-uniform, rarely taken
-            const bool mine = (cand >> lane) & 1ull;
+            // lane masks are formed here, from a laundered lane id, and not kept in registers across the sweeps
+            int ln = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(ln));
+#endif
+            const uint64_t rowmask = 0xffffull << (ln & 48);
+            const bool mine = (cand >> ln) & 1ull;
             bool anyv = false;
             if (mine) {
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
                     const bool viol = gene_ok && 16 * u + i < K && S.inv[u] == 0.0 && fabs(S.h[u]) > la;
-                    if (viol) S.inv[u] = cd_rcp(s_d[64 * u]);                               // :123
+                    if (viol) S.inv[u] = s_ri[64 * u];                                      // :123
                     anyv = anyv || viol;
                 }
             }
@@ -310,12 +339,14 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
             unfinished = true;
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) { hs[u] = S.h[u]; is[u] = S.inv[u]; }
-            // |loss change| decays geometrically: rho^W = b / a over the last two W-sweep windows; sweeps until it reaches tol
-            const double wa = s_acc[0], wb = s_acc[64], wt = (double)W * tol;
-            double est = 1048576.0;
-            if (wa > wb && wb > wt) est = (double)W * log(wb / wt) / log(wa / wb);
-            else if (wb <= wt) est = 1.0;
-            key = (int)fmin(fmax(est, 1.0), 1048576.0);
+            // |loss change| decays geometrically: rho^W = b / a over the last two W-sweep windows; sweeps until it reaches tol.
+            // Single precision: the estimate only picks a bucket of the next pass's launch order (8 per octave), never a result,
+            // and a double-precision log would cost ~20 registers next to the Gram matrix
+            const float wa = (float)s_acc[0], wb = (float)s_acc[64], wt = (float)((double)W * tol);
+            float est = 1048576.0f;
+            if (wa > wb && wb > wt) est = (float)W * __logf(wb / wt) / __logf(wa / wb);
+            else if (wb <= wt) est = 1.0f;
+            key = (int)fminf(fmaxf(est, 1.0f), 1048576.0f);
         } else {
             capped = true;   // the sweep cap ended the solve, not convergence (the reference loops on, :86-114)
         }
@@ -328,118 +359,187 @@ __device__ __forceinline__ int cd_reg(const double (&G)[SLOTS][KMAX], int K, con
 // ---------------------------------------------------------------------------------------------
 // Kernel: column update with the register-resident solver (K <= 32); same contract as k_cd_cols
 // ---------------------------------------------------------------------------------------------
-template <int SLOTS, int KMAX>
+// Register discipline (round 3).  The 128-VGPR builds of this kernel computed wrong results twice (KMAX = 22 in round 2,
+// KMAX = 20 in round 3) when an unrelated edit moved the register allocation: the allocator had placed the spill STORE of a
+// value that is live in all lanes (the gene's row offset j * KP) inside an exec-masked region — the `if (16 + i < K)` body
+// that loaded the second coordinate slot — so only the lanes active there saved it; the reload after the sweep loop ran under
+// the full mask, the other lanes formed the addresses of their result stores from stale scratch, and the solution (right in
+// registers: the loss statistics agreed with the CPU check) went to the wrong place.  Nothing in the sweep assembly is involved.
+// The kernel is therefore written so that NOTHING needs spilling and no spill could land in a masked region:
+//  * what addresses the gene (row, slot, gene id, record pointer) is recomputed after the loop from a laundered lane id
+//    instead of being kept alive across it, and the loss statistics reload q and the diagonal instead of holding them;
+//  * every load of the prologue is unconditional (absent genes read gene 0, absent coordinates a valid address; the
+//    values are masked), so the prologue has no divergent region at all;
+//  * tests/test_lib_cpu.py disassembles the shipped code object and fails on ANY scratch instruction in these kernels
+//    (K <= 30) and on any spill store under a narrowed exec mask anywhere in the library (tools/spill_scan.py).
+struct RegWho {            // which gene a lane works for
+    int i, j;              // coordinate lane inside the row; gene (0 when the row holds none: every pointer stays valid)
+    bool gene;             // the row holds a gene
+    const double *st;      // its statistics record, or null (tuning == 0; wave-uniform nullness)
+};
+
+__device__ __forceinline__ RegWho reg_who(const ColArgs &a, int lane)
+{
+    RegWho w;
+    const int row = lane >> 4, slot = blockIdx.x * 4 + row;
+    w.i = lane & 15;
+    // a resumed pass (multi-pass solve) continues the genes the previous pass left unfinished: the first *pass_count of its order
+    const int count = a.pass_count ? *a.pass_count : a.p;
+    w.gene = slot < a.p && slot < count;
+    const int sl = w.gene ? slot : 0;
+    const int jj = a.gene_perm ? a.gene_perm[sl] : sl;
+    w.j = w.gene ? jj : 0;
+    w.st = a.stat ? a.stat + (size_t)w.j * a.stat_len : nullptr;
+    return w;
+}
+
+// q = X'y over the gene's training entries (src/optimize.cpp:222,235 via level sums, minus the held-out part), XtX_kk
+template <int SLOTS>
+__device__ __forceinline__ void reg_load_q(const ColArgs &a, const RegWho &w, double (&q)[SLOTS], double (&Gll)[SLOTS])
+{
+    const int K = a.K, KP = a.KP;
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int c = 16 * u + w.i;                 // < KP: always a valid address
+        const bool ok = w.gene && c < K;
+        double qv = a.Qfull[(size_t)w.j * KP + c];
+        if (w.st) qv -= w.st[stat_index(KP - 1, c)];
+        const double d = w.st ? w.st[stat_index(c, c)] : a.RtR[c * KP + c];
+        q[u] = ok ? qv : 0.0;
+        Gll[u] = ok ? d : 1.0;
+    }
+}
+
+// SOLVE: the elastic-net solve (a.mode == COL_CD), results and counters only; !SOLVE: the per-gene loss statistics of the
+// column as it stands (a.checkpoint; evaluate() / compute_loss(), src/utils.cpp:56-102).  Two kernels instead of one with both
+// parts: the statistics need q, the diagonal and two matrix-vector products next to the 2 x KMAX matrix registers, which the
+// solve kernel's register budget (set by the sweep loop) does not have; a checkpoint costs one more matrix load per gene
+// every tenth outer iteration.
+template <int SLOTS, int KMAX, bool SOLVE>
 __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
 {
     const int lane = threadIdx.x;
-    const int row = lane >> 4, i = lane & 15;
     const int K = a.K, KP = a.KP;
-    const int slot = blockIdx.x * 4 + row;
-    const int j = slot < a.p ? (a.gene_perm ? a.gene_perm[slot] : slot) : a.p;
-    // a resumed pass (multi-pass solve) continues the genes the previous pass left unfinished: the first *pass_count of its order
     const bool resume = a.pass_count != nullptr;
-    const bool gene = j < a.p && (!resume || slot < *a.pass_count);
-    if (resume && __ballot(gene) == 0) return;
     __shared__ double stash[REG_STASH];
-    const double *st = (a.stat && gene) ? a.stat + (size_t)j * a.stat_len : nullptr;
-    // XtX_j = R'R - complement (src/optimize.cpp:218-219: the statistics record holds it ready-made), or the shared R'R
-    // (:234); zero diagonal in registers.  One operand stream per element: two would make the allocator spill the matrix.
-    double G[SLOTS][KMAX], q[SLOTS], Gll[SLOTS], beta[SLOTS];
+    double G[SLOTS][KMAX], beta[SLOTS], hs[SLOTS], is[SLOTS];
+    bool unfinished = false, capped = false;
+    int key = 0, sweeps = 0;
+    {
+        const RegWho w = reg_who(a, lane);
+        if (resume && __ballot(w.gene) == 0) return;
+        // start values first, the matrix afterwards: their inputs and the 2 x KMAX matrix registers are never live together
+        RegState<SLOTS> S;
+        {
+            double q[SLOTS], Gll[SLOTS];
+            reg_load_q<SLOTS>(a, w, q, Gll);
 #pragma unroll
-    for (int u = 0; u < SLOTS; ++u) {
-        const int c = 16 * u + i;
-        const bool ok = gene && c < K;
-        Gll[u] = 1.0;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            // element (k, c) of the lower-block-stored statistics (stat_index with the block pair known statically)
-            const int bk = k >> 4;
-            const int si = bk >= u ? (bk * (bk + 1) / 2 + u) * 256 + (k & 15) * 16 + i
-                                   : (u * (u + 1) / 2 + bk) * 256 + i * 16 + (k & 15);
-            const double v = st ? st[si] : a.RtR[k * KP + c];
-            G[u][k] = (ok && k < K && k != c) ? v : 0.0;
-        }
-        q[u] = 0.0;
-        beta[u] = 0.0;
-        if (ok) {
-            Gll[u] = st ? st[stat_index(c, c)] : a.RtR[c * KP + c];
-            q[u] = a.Qfull[(size_t)j * KP + c];                                          // :222,235 via level sums
-            if (st) q[u] -= st[stat_index(KP - 1, c)];                                   // minus the held-out part
-            beta[u] = a.C[(size_t)j * KP + c];
-        }
-    }
-    bool done = gene;      // the rows whose solve ends in this launch: they own the results and the loss statistics
-    if (a.mode == COL_CD) {                                                              // :228,246
-        double hs[SLOTS], is[SLOTS];
-#pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
-            const bool ld = resume && gene && 16 * u + i < K;
-            hs[u] = ld ? a.hsave[(size_t)j * KP + 16 * u + i] : 0.0;
-            is[u] = ld ? a.isave[(size_t)j * KP + 16 * u + i] : 0.0;
-        }
-        bool unfinished, capped;
-        int key;
-        const int sweeps = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, gene, a.cd, lane, stash, resume, hs, is, unfinished, key, capped);
-#pragma unroll
-        for (int u = 0; u < SLOTS; ++u)
-            if (gene && 16 * u + i < K) {
-                a.C[(size_t)j * KP + 16 * u + i] = beta[u];
-                if (unfinished) {
-                    a.hsave[(size_t)j * KP + 16 * u + i] = hs[u];
-                    a.isave[(size_t)j * KP + 16 * u + i] = is[u];
+            for (int u = 0; u < SLOTS; ++u) {
+                const int c = 16 * u + w.i;
+                const bool ok = w.gene && c < K;
+                const double b = a.C[(size_t)w.j * KP + c];
+                beta[u] = ok ? b : 0.0;
+                hs[u] = 0.0;
+                is[u] = 0.0;
+                if (resume) {                                                             // wave-uniform
+                    const double hv = a.hsave[(size_t)w.j * KP + c], iv = a.isave[(size_t)w.j * KP + c];
+                    hs[u] = ok ? hv : 0.0;
+                    is[u] = ok ? iv : 0.0;
                 }
             }
-        done = gene && !unfinished;
-        if (gene && i == 0) {
+            if constexpr (SOLVE) S = cd_reg_begin<SLOTS>(K, q, Gll, beta, w.gene, a.cd, lane, stash, resume, hs, is);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");   // the matrix loads stay below the start values
+#endif
+        // XtX_j = R'R - complement (src/optimize.cpp:218-219: the statistics record holds it ready-made), or the shared R'R
+        // (:234); zero diagonal in registers.  One operand stream per element: two would make the allocator spill the matrix.
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int c = 16 * u + w.i;
+            const bool ok = w.gene && c < K;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                // element (k, c) of the lower-block-stored statistics (stat_index with the block pair known statically)
+                const int bk = k >> 4;
+                const int si = bk >= u ? (bk * (bk + 1) / 2 + u) * 256 + (k & 15) * 16 + w.i
+                                       : (u * (u + 1) / 2 + bk) * 256 + w.i * 16 + (k & 15);
+                const double v = w.st ? w.st[si] : a.RtR[k * KP + c];
+                G[u][k] = (ok && k < K && k != c) ? v : 0.0;
+            }
+        }
+        if constexpr (SOLVE)                                                              // :228,246
+            sweeps = cd_reg<SLOTS, KMAX>(S, G, K, beta, w.gene, a.cd, lane, stash, resume, hs, is, unfinished, key, capped);
+    }
+    // ---- results: everything that addresses the gene is formed again, from a laundered lane id ------------------------
+    int lane_c = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane_c));
+#endif
+    const RegWho w = reg_who(a, lane_c);
+    if constexpr (SOLVE) {
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u)
+            if (w.gene && 16 * u + w.i < K) {
+                a.C[(size_t)w.j * KP + 16 * u + w.i] = beta[u];
+                if (unfinished) {
+                    a.hsave[(size_t)w.j * KP + 16 * u + w.i] = hs[u];
+                    a.isave[(size_t)w.j * KP + 16 * u + w.i] = is[u];
+                }
+            }
+        if (w.gene && w.i == 0) {
             if (unfinished) {
                 const int b = cd_bucket(key);
-                a.pass_slot[j] = ((uint32_t)b << 24) | (uint32_t)atomicAdd(&a.bucket_cnt[b], 1);
+                a.pass_slot[w.j] = ((uint32_t)b << 24) | (uint32_t)atomicAdd(&a.bucket_cnt[b], 1);
             } else {
-                if (a.pass_slot) a.pass_slot[j] = CD_PASS_DONE;
+                if (a.pass_slot) a.pass_slot[w.j] = CD_PASS_DONE;
+#ifndef INSIDER_NO_CAP_COUNT   // (diagnostic builds only, tools/k20_variants.sh)
                 if (a.cap_hits) {
                     if (capped) atomicAdd(a.cap_hits, 1);
                     if (sweeps > a.cap_hits[1]) atomicMax(a.cap_hits + 1, sweeps);   // longest solve of the call
                 }
-                a.sweeps[j] = sweeps;
+#endif
+                a.sweeps[w.j] = sweeps;
                 if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
             }
         }
+        return;
     }
-    if (!a.checkpoint) return;
-    // ---- loss statistics with the (updated) column: fresh g = q - XtX beta ---------------------------------------------
-    double g[SLOTS];
+    // ---- loss statistics with the column as it stands: fresh g = q - XtX beta -------------------------------------------
+    double q[SLOTS], Gll[SLOTS], g[SLOTS];
+    reg_load_q<SLOTS>(a, w, q, Gll);
 #pragma unroll
-    for (int u = 0; u < SLOTS; ++u) g[u] = (gene && 16 * u + i < K) ? q[u] - Gll[u] * beta[u] : 0.0;
+    for (int u = 0; u < SLOTS; ++u) g[u] = (w.gene && 16 * u + w.i < K) ? q[u] - Gll[u] * beta[u] : 0.0;
     reg_gemv<SLOTS, KMAX>(g, beta, G, K);
     double t_bqg = 0.0, t_b2 = 0.0, t_b1 = 0.0, t_te = 0.0;
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
-        if (gene && 16 * u + i < K) {
+        if (w.gene && 16 * u + w.i < K) {
             t_bqg += beta[u] * (q[u] + g[u]);
             t_b2 += beta[u] * beta[u];
             t_b1 += fabs(beta[u]);
         }
     }
-    if (a.test_from_stats && st) {
+    if (a.test_from_stats && w.st) {
         // sum_test (x - r'b)^2 = sum_held x^2 - 2 b'qc + b'(R'R b) - b'(q - g)      (see k_cd_cols)
         double rb[SLOTS];
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) rb[u] = 0.0;
-#define R16_D(M) r16_dense_mv_step<SLOTS, M>(rb, beta, a.RtR, KP, K, i, gene);
+#define R16_D(M) r16_dense_mv_step<SLOTS, M>(rb, beta, a.RtR, KP, K, w.i, w.gene);
         R16_UNROLL32(R16_D)
 #undef R16_D
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
-            const int c = 16 * u + i;
-            if (gene && c < K) t_te += beta[u] * (rb[u] - (q[u] - g[u]) - 2.0 * st[stat_index(KP - 1, c)]);
+            const int c = 16 * u + w.i;
+            if (w.gene && c < K) t_te += beta[u] * (rb[u] - (q[u] - g[u]) - 2.0 * w.st[stat_index(KP - 1, c)]);
         }
     }
     const double bqg = row16_sum(t_bqg), sb2 = row16_sum(t_b2), sb1 = row16_sum(t_b1), te = row16_sum(t_te);
-    if (done && i == 0) {
-        a.sse_train[j] = a.yy[j] - bqg;
-        a.b2[j] = sb2;
-        a.b1[j] = sb1;
-        if (a.test_from_stats) a.sse_test[j] = st ? st[stat_index(KP - 1, KP - 1)] + te : 0.0;
+    if (w.gene && w.i == 0) {
+        a.sse_train[w.j] = a.yy[w.j] - bqg;
+        a.b2[w.j] = sb2;
+        a.b1[w.j] = sb1;
+        if (a.test_from_stats) a.sse_test[w.j] = w.st ? w.st[stat_index(KP - 1, KP - 1)] + te : 0.0;
     }
 }
 
@@ -450,30 +550,57 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
                int64_t nprob, CdParams cd, double *__restrict__ beta_out, int *__restrict__ sweeps_out)
 {
     const int lane = threadIdx.x;
-    const int row = lane >> 4, i = lane & 15;
+    __shared__ double stash[REG_STASH];
+    double G[SLOTS][KMAX], beta[SLOTS];
+    int sw;
+    {
+        const int row = lane >> 4, i = lane & 15;
+        const int64_t b = (int64_t)blockIdx.x * 4 + row;
+        const bool prob = b < nprob;
+        const double *Gb = XtX + (size_t)(prob ? b : 0) * K * K;     // absent problems read problem 0: every load unconditional
+        const double *qb = Xty + (size_t)(prob ? b : 0) * K, *wb = wstart + (size_t)(prob ? b : 0) * K;
+        double hs[SLOTS], is[SLOTS];
+        RegState<SLOTS> S;
+        {
+            double q[SLOTS], Gll[SLOTS];
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) {
+                const int c = 16 * u + i;
+                const bool ok = prob && c < K;
+                const int cc = c < K ? c : 0;
+                const double dv = Gb[(size_t)cc * K + cc], qv = qb[cc], wv = wb[cc];
+                Gll[u] = ok ? dv : 1.0;
+                q[u] = ok ? qv : 0.0;
+                beta[u] = ok ? wv : 0.0;
+                hs[u] = is[u] = 0.0;
+            }
+            S = cd_reg_begin<SLOTS>(K, q, Gll, beta, prob, cd, lane, stash, false, hs, is);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");   // the matrix loads stay below the start values
+#endif
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int c = 16 * u + i;
+            const bool ok = prob && c < K;
+            const int cc = c < K ? c : 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const double v = Gb[(size_t)(k < K ? k : 0) * K + cc];
+                G[u][k] = (ok && k < K && k != c) ? v : 0.0;
+            }
+        }
+        bool unfinished, capped;
+        int key;
+        sw = cd_reg<SLOTS, KMAX>(S, G, K, beta, prob, cd, lane, stash, false, hs, is, unfinished, key, capped);
+    }
+    int lane_c = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane_c));
+#endif
+    const int row = lane_c >> 4, i = lane_c & 15;
     const int64_t b = (int64_t)blockIdx.x * 4 + row;
     const bool prob = b < nprob;
-    __shared__ double stash[REG_STASH];
-    const double *Gb = XtX + (size_t)(prob ? b : 0) * K * K;
-    double G[SLOTS][KMAX], q[SLOTS], Gll[SLOTS], beta[SLOTS];
-#pragma unroll
-    for (int u = 0; u < SLOTS; ++u) {
-        const int c = 16 * u + i;
-        const bool ok = prob && c < K;
-        const int cc = c < K ? c : 0;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const double v = Gb[(size_t)(k < K ? k : 0) * K + cc];
-            G[u][k] = (ok && k < K && k != c) ? v : 0.0;
-        }
-        Gll[u] = ok ? XtX[(size_t)b * K * K + (size_t)c * K + c] : 1.0;
-        q[u] = ok ? Xty[(size_t)b * K + c] : 0.0;
-        beta[u] = ok ? wstart[(size_t)b * K + c] : 0.0;
-    }
-    double hs[SLOTS], is[SLOTS];
-    bool unfinished, capped;
-    int key;
-    const int sw = cd_reg<SLOTS, KMAX>(G, K, q, Gll, beta, prob, cd, lane, stash, false, hs, is, unfinished, key, capped);
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u)
         if (prob && 16 * u + i < K) beta_out[(size_t)b * K + 16 * u + i] = beta[u];

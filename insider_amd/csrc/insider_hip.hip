@@ -551,6 +551,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
+    bool eval_after = false;
+    ColArgs eval_args;
     if (alpha == 0.0) {
         RidgeArgs a;
         a.stat = masked ? h->stat_col : nullptr;
@@ -647,7 +649,7 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
                 a.pass_slot = npass ? h->cd_pass_slot : nullptr;
                 a.bucket_cnt = limit ? h->cd_pass_cnt : nullptr;
                 if (limit) HIPCHECK(hipMemsetAsync(h->cd_pass_cnt, 0, CD_BUCKETS * sizeof(int), h->stream));
-                REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a));
+                if (solve) { REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, true>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a)); }
                 KCHECK();
                 if (!limit) break;
                 int *count_out = h->cd_pass_cnt + CD_BUCKETS + (pass & 1);
@@ -659,6 +661,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
                 a.pass_count = count_out;
                 start = limit;
             }
+            eval_after = checkpoint != 0;
+            eval_args = a;
         } else if (h->cd_variant == 2 && h->K <= 16)
             hipLaunchKernelGGL((k_cd_cols_r16<1>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
         else if (h->cd_variant == 2 && h->K <= 32)
@@ -669,6 +673,12 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         KCHECK();
     }
     if ((rc = t.end(h, h->ev_cd))) return rc;
+    if (eval_after) {   // the per-gene loss statistics of the (updated) columns: the evaluation kernel, all genes (not part of the solve's time)
+        eval_args.gene_perm = nullptr;
+        eval_args.pass_count = nullptr;
+        REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, false>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, eval_args));
+        KCHECK();
+    }
     if (solve && alpha != 0.0) {
         // schedule the next solve longest-first, genes of similar length sharing a wave (stable sort: deterministic)
         hipStream_t st = h->stream;

@@ -42,6 +42,9 @@ def parse(argv=None):
     ap.add_argument("--lambdas", type=float, nargs="+")
     ap.add_argument("--alphas", type=float, nargs="+")
     ap.add_argument("--tuning-iter", type=int, default=30)
+    ap.add_argument("--warm-start", action="store_true",
+                    help="--tune: start every (lambda, alpha) grid point from its nearest finished neighbour's factors "
+                         "(opt-in; the reference draws fresh inits per point, R/insider.R:152-161)")
     ap.add_argument("--split-ratio", type=float, default=0.1)
     ap.add_argument("--out", default="insider_fit_out")
     ap.add_argument("--out-format", choices=("npy", "flat"), default=None)
@@ -89,7 +92,7 @@ def main(argv=None):
         res = api.tune(obj, latent_dimension=np.array(a.ranks if a.ranks else [a.rank]),
                        lambda_=a.lambdas if a.lambdas else (a.lam if a.lam is not None else 0.1),
                        alpha=a.alphas if a.alphas else (a.alpha if a.alpha is not None else 0.0), out_dir=None,
-                       rng=np.random.default_rng(a.seed))
+                       rng=np.random.default_rng(a.seed), warm_start=a.warm_start)
         os.makedirs(a.out, exist_ok=True)
         out = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in res.items()}
         with open(os.path.join(a.out, "tune.json"), "w") as f:

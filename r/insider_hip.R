@@ -1,7 +1,8 @@
 # insider_hip.R — R side of the MI355X path for kai0511/insider: source() it after library(insider), or copy it into
 # the package's R/ directory in place of the two wrappers it re-points (R/RcppExports.R:8-10,20-22).
 # Needs r/insider_hip_shim.c built against libinsider_hip.so (see that file's header).  Not runnable in this
-# repository's pipeline (no R in the image); the same C ABI is exercised through ctypes by tests/test_gpu_boundary.py.
+# repository's pipeline (no R in the image); the shim is compiled and executed against a stand-in for the R C API by
+# tests/test_r_shim.py, the same C ABI through ctypes by tests/test_gpu_boundary.py.
 
 insider_hip_load <- function(dir = Sys.getenv("INSIDER_HIP_DIR", ".")) {
     dyn.load(file.path(dir, "libinsider_hip.so"), local = FALSE)   # the C ABI (include/insider_hip.h)
@@ -13,29 +14,61 @@ insider_hip_available <- function() {
     is.loaded("insider_hip_available_R") && isTRUE(.Call("insider_hip_available_R"))
 }
 
-# optimize(): R/RcppExports.R:20-22 with the same 16 arguments (+ seed, device).  Every combination the reference
-# accepts goes to the GPU, continuous covariates included; the CPU reference is used only when no MI355X is visible.
+# optimize(): R/RcppExports.R:20-22 with the same 16 arguments (+ seed, device, resident).  Every combination the
+# reference accepts goes to the GPU, continuous covariates included.  resident = TRUE (default): the data set stays in HBM
+# across calls — the shim caches the library handle on the identity of (data, cfd_indicators, train_indicator,
+# test_indicator, ctns_confounder), so the reference's UNMODIFIED tune() loop (R/insider.R:142-174), which calls optimize()
+# once per grid point with the same objects, uploads X once.  insider_hip_cache_clear() frees the cached data sets.
+# The CPU reference is used when no MI355X is visible or the problem is outside the library's limits (K > 63, n or
+# p >= 2^23): the .Call then returns NULL (with a warning) instead of raising an error.
 optimize <- function(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, train_indicator,
                      test_indicator, inc_continuous, latent_dim, lambda1 = 1.0, lambda2 = 1.0, alpha = 0.1,
                      tuning = 1L, global_tol = 1e-10, sub_tol = 1e-5, max_iter = 10000L,
-                     seed = sample.int(.Machine$integer.max, 1), device = 0L) {
+                     seed = sample.int(.Machine$integer.max, 1), device = 0L, resident = TRUE) {
+    res <- NULL
     if (insider_hip_available())
-        .Call("insider_hip_optimize_R", data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
-              train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
-              global_tol, sub_tol, max_iter, seed, device)
-    else
-        .Call(`_insider_optimize`, data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
-              train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
-              global_tol, sub_tol, max_iter)
+        res <- .Call("insider_hip_optimize_R", data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
+                     train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
+                     global_tol, sub_tol, max_iter, seed, device, as.integer(resident))
+    if (is.null(res))
+        res <- .Call(`_insider_optimize`, data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
+                     train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
+                     global_tol, sub_tol, max_iter)
+    res
 }
+
+insider_hip_cache_clear <- function() invisible(.Call("insider_hip_cache_clear_R"))
+insider_hip_cache_stats <- function() setNames(.Call("insider_hip_cache_stats_R"), c("hits", "misses", "live"))
+
+# Explicit handles, for callers that manage residency themselves: h <- insider_hip_create(object, latent_dimension);
+# insider_hip_optimize_handle(h, cfd_factors, column_factor, ...) per grid point; the handle frees its HBM when it is
+# garbage-collected or on insider_hip_destroy(h).
+insider_hip_create <- function(object, cfd_factors, latent_dim, tuning_masks = TRUE, device = 0L) {
+    tr <- if (tuning_masks) object$train_indicator else object$train_indicator + object$test_indicator   # R/insider.R:207-208
+    te <- if (tuning_masks) object$test_indicator else object$na_indicator
+    .Call("insider_hip_create_R", object$data, cfd_factors, object$confounder, object$ctns_confounder, tr, te,
+          as.integer(object$inc_continuous), as.integer(latent_dim), as.integer(device))
+}
+
+insider_hip_optimize_handle <- function(handle, cfd_factors, column_factor, n_covariates, inc_continuous, latent_dim,
+                                        lambda1 = 1.0, lambda2 = 1.0, alpha = 0.1, tuning = 1L, global_tol = 1e-10,
+                                        sub_tol = 1e-5, max_iter = 10000L, seed = sample.int(.Machine$integer.max, 1)) {
+    .Call("insider_hip_optimize_handle_R", handle, cfd_factors, column_factor, as.integer(n_covariates),
+          as.integer(inc_continuous), as.integer(latent_dim), lambda1, lambda2, alpha, as.integer(tuning), global_tol,
+          sub_tol, max_iter, seed)
+}
+
+insider_hip_destroy <- function(handle) invisible(.Call("insider_hip_destroy_R", handle))
 
 # strong_coordinate_descent(): R/RcppExports.R:8-10.  XtX / Xty may be NULL (formed on the device from X, y).
 strong_coordinate_descent <- function(X, y, wstart, lambda, alpha, XtX = NULL, Xty = NULL, tol = 1e-5,
                                       seed = sample.int(.Machine$integer.max, 1), device = 0L) {
+    res <- NULL
     if (insider_hip_available())
-        .Call("insider_hip_strong_cd_R", X, y, wstart, lambda, alpha, XtX, Xty, tol, seed, device)
-    else
-        .Call(`_insider_strong_coordinate_descent`, X, y, wstart, lambda, alpha, XtX, Xty, tol)
+        res <- .Call("insider_hip_strong_cd_R", X, y, wstart, lambda, alpha, XtX, Xty, tol, seed, device)
+    if (is.null(res))
+        res <- .Call(`_insider_strong_coordinate_descent`, X, y, wstart, lambda, alpha, XtX, Xty, tol)
+    res
 }
 
 # ---- .RData-free exchange with `python -m insider_amd.fit` (insider_amd/flatio.py reads / writes the same layout) ----

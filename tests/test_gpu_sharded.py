@@ -159,3 +159,72 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert two["loss"] == pytest.approx(one["loss"], rel=1e-10) and two["test_rmse"] == pytest.approx(one["test_rmse"], rel=1e-10)
     for key in ("roofline", "masked_gram", "cd_kernel"):
         assert key in two and two["roofline"]["frac"] <= 1.0
+
+
+# ---- grid-parallel tune() on real handles: every rank keeps the WHOLE data set resident on the GPU and
+# fits the grid points g % world == rank; the result tables are summed over torch.distributed -----------------------------
+TUNE_CASE = dict(n=96, p=140, level_counts=(6, 4), K=6, f=0.15, seed=31)
+
+
+def _tune_real(rank, world, warm_start=False):
+    from insider_amd import api
+    w = workloads.small(**TUNE_CASE)
+    obj = api.Insider(data=w.X, confounder=w.levels, inc_continuous=0, ctns_confounder=None, train_indicator=w.M_train,
+                      test_indicator=w.M_test, seed=13,
+                      params=dict(global_tol=1e-9, sub_tol=1e-5, tuning_iter=6, max_iter=50))
+    out = api.tune(obj, latent_dimension=np.array([4, 6]), lambda_=[1.0, 2.0, 4.0], alpha=[0.2, 0.5],
+                   rng=np.random.default_rng(5), rank=rank, world=world, warm_start=warm_start)
+    obj["_resident_tune"].close()
+    return out
+
+
+def _tune_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = _tune_real(rank, world)
+        q.put((rank, dict(rank_tuning=out["rank_tuning"], latent_rank=out["latent_rank"], reg_tuning=out["reg_tuning"])))
+    except Exception as e:
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grid_parallel_tune_on_real_handles_matches_serial():
+    """Two processes, each with its own resident InsiderData on the one GPU, split tune()'s rank sweep and lambda x alpha
+    grid between them (gloo sum of the tables): both end with exactly the serial run's tables, because every rank draws
+    every point's fresh inits in the reference's order and each fit is an independent, deterministic call."""
+    serial = _tune_real(0, 1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tune_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert isinstance(out[r], dict), out[r]
+        assert out[r]["latent_rank"] == serial["latent_rank"]
+        np.testing.assert_array_equal(out[r]["rank_tuning"], serial["rank_tuning"])
+        np.testing.assert_array_equal(out[r]["reg_tuning"], serial["reg_tuning"])
+    assert serial["reg_tuning"].shape == (6, 4) and np.all(np.isfinite(serial["reg_tuning"]))
+
+
+def test_tune_warm_start_is_opt_in_and_close_to_cold():
+    """warm_start=True starts each grid point from its nearest finished neighbour: the first point is identical to the cold
+    run (it has no neighbour), the others reach test RMSEs close to the cold run's within the same iteration budget, and
+    the default stays the reference's fresh inits."""
+    cold = _tune_real(0, 1)
+    cold2 = _tune_real(0, 1)
+    warm = _tune_real(0, 1, warm_start=True)
+    np.testing.assert_array_equal(cold["reg_tuning"], cold2["reg_tuning"])              # default path: deterministic
+    np.testing.assert_array_equal(warm["rank_tuning"], cold["rank_tuning"])            # the rank sweep is not warm-started
+    np.testing.assert_array_equal(warm["reg_tuning"][0], cold["reg_tuning"][0])
+    assert not np.array_equal(warm["reg_tuning"][1:], cold["reg_tuning"][1:])
+    assert np.max(np.abs(warm["reg_tuning"][:, 3] - cold["reg_tuning"][:, 3])) < 0.05 * np.max(cold["reg_tuning"][:, 3])

@@ -114,15 +114,21 @@ def test_workload_configs():
     assert np.array_equal(slab.X, full.X[:, 1000:2100]) and np.array_equal(slab.M_train, full.M_train[:, 1000:2100])
 
 
-def test_sweep_loops_are_free_of_scratch_traffic(tmp_path, lib):
-    """The register-resident sweep kernels (insider_cd_reg.hpp) are sized so that nothing is spilled INSIDE the sweep loop:
-    a reload per sweep costs about as much as the sweep.  (The one build that also computed wrong iterates, KMAX = 22 under
-    the 128-VGPR budget in round 2, had such a reload at its loop head; parity tests caught it, this is the cheap canary.)
-    Disassembles the shipped code object and checks the sweep loop of every instantiation up to KMAX = 30 (K <= 30 covers the
-    BASELINE configurations); KMAX = 32 is known to reload one Gram element per sweep at the 168-VGPR budget."""
+def test_sweep_kernels_do_not_spill(tmp_path, lib):
+    """The register-resident sweep kernels (insider_cd_reg.hpp) must not spill.
+
+    Twice (KMAX = 22 in round 2, KMAX = 20 in round 3) a 128-VGPR build of the column-update kernel wrote its results to
+    wrong addresses: the register allocator had put the spill STORE of a value live in all lanes inside an exec-masked
+    region, the reload ran under the full mask, and the lanes that had been masked off used stale scratch.  The kernels are
+    now written so that nothing needs spilling; this test disassembles the shipped code object and checks that
+      * every instantiation up to KMAX = 30 (K <= 30 covers the BASELINE configurations) contains NO scratch instruction at
+        all, the solve kernels (with their sweep loop), the evaluation kernels and the stand-alone batch solver alike;
+      * KMAX = 32 (168 VGPRs for 128 matrix registers) keeps its sweep loop free of scratch traffic;
+      * no kernel of the whole library stores a spill under a narrowed exec mask (tools/spill_scan.py)."""
     import re as _re
     import shutil
     import subprocess
+    import sys as _sys
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not available")
@@ -132,21 +138,34 @@ def test_sweep_loops_are_free_of_scratch_traffic(tmp_path, lib):
     co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
     assert co, "no gfx950 code object in the library"
     dis = subprocess.run([objdump, "-d", str(tmp_path / co[0])], check=True, capture_output=True, text=True).stdout
+    _sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import spill_scan
+    masked = {k: v for k, v in spill_scan.scan(dis).items() if v[1]}
+    assert not masked, {k: v[2][:2] for k, v in masked.items()}
     # label -> address (kernels and the local labels of the sweep assembly, which split a kernel's listing)
     labels = {m.group(2): int(m.group(1), 16) for m in _re.finditer(r"^([0-9a-f]{16}) <([^>]+)>:", dis, _re.M)}
     funcs = _re.split(r"\n(?=[0-9a-f]{16} <_Z)", dis)
-    loops = 0
+    loops = kernels = 0
     for fn in funcs:
         head = fn.split("\n", 1)[0]
         if "k_cd_cols_reg" not in head and "k_cd_batch_reg" not in head:
             continue
+        kernels += 1
+        kmax = int(_re.search(r"ILi[12]ELi(\d+)E", head).group(1))
         ins = []                                   # (address, instruction, rest of the line: branch targets live there)
         for line in fn.split("\n")[1:]:
             m = _re.search(r"^\s*(\S.*?)\s*//\s*([0-9A-Fa-f]+):(.*)$", line)
             if m:
                 ins.append((int(m.group(2), 16), m.group(1), m.group(3)))
-        sites = [i for i, (_, t, _r) in enumerate(ins) if t.startswith("s_load_dwordx16 s[64:79]")]
-        assert len(sites) == 1, (head, len(sites))
+        scratch = [t for _a, t, _r in ins if t.startswith(("scratch_", "buffer_load", "buffer_store"))]
+        if kmax <= 30:
+            assert not scratch, (head, scratch[:4])
+        # the sweep's prologue: its table loads end with the s_getpc_b64 that anchors the code-block table
+        sites = [i - 3 for i, (_, t, _r) in enumerate(ins) if t.startswith("s_getpc_b64 s[98:99]")]
+        if "k_cd_cols_reg" in head and "ELb0E" in head:
+            assert not sites, head                 # the evaluation kernels have no sweep loop
+            continue
+        assert len(sites) == 1 and ins[sites[0]][1].startswith("s_load_dwordx16 s[64:79]"), (head, len(sites))
         a0 = ins[sites[0]][0]
         # the loop's back edge: the first branch after the sweep whose target lies at or shortly before the sweep's first load
         back = None
@@ -162,13 +181,9 @@ def test_sweep_loops_are_free_of_scratch_traffic(tmp_path, lib):
         body = [t for addr, t, _r in ins[: back[0] + 1] if addr >= back[1]]
         assert len(body) > 100, (head, len(body))                     # the whole sweep (code blocks + loss bookkeeping) is in it
         spills = [t for t in body if t.startswith(("scratch_", "buffer_load", "buffer_store"))]
-        kmax = int(_re.search(r"ILi[12]ELi(\d+)E", head).group(1))
-        if kmax <= 30:
-            assert not spills, (head, spills[:4])
-        else:
-            assert all(t.startswith("scratch_load") for t in spills) and len(spills) <= 2, (head, spills[:4])
+        assert not spills, (head, spills[:4])
         loops += 1
-    assert loops == 18, loops                      # 9 register budgets x {column update, stand-alone batch solver}
+    assert loops == 18 and kernels == 27, (loops, kernels)   # 9 register budgets x {solve, evaluate, stand-alone batch solver}
 
 
 def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
