@@ -109,6 +109,41 @@ def test_c5_structure_full_n_slab_vs_oracle(c5_slab, paths):
     _check_slab(c5_slab, paths, [20, 200, 10, 25])
 
 
+def test_c3_structure_deep_sweeps_uncapped_vs_oracle():
+    """The deep-sweep regime at real size, which the capped slab tests above never reach: c3's structure at full n (10000
+    samples, 100 x 10 levels, K = 30, 10 % held out), 64 genes, the reference's cold N(0, 1e-6) inits, two outer
+    iterations with a sweep cap far above anything reached (the reference has none, src/coordinate_descent.cpp:86-114) — the
+    first iteration of such a call runs thousands of sweeps per gene through the multi-pass continuation
+    [64, 256) -> [256, 1024) -> [1024, 4096) -> [4096, end) of the default path.  Same sweeps (total within 1 per solve),
+    same factors, same trajectory as the oracle's residual-form CD; no solve may end at the cap."""
+    from oracle import c_oracle
+    genes, cap = 64, 100000
+    w = workloads.make("c3", gene_range=(0, genes))
+    assert w.n == 10000 and list(w.n_levels) == [100, 10] and w.K == 30
+    c_oracle.set_col_chunk(1)
+    try:
+        threads = c_oracle.num_procs()
+        ref = c_oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                                max_iter=1, seed=41, max_sweeps=cap, col_threads=threads, row_threads=threads)
+    finally:
+        c_oracle.set_col_chunk(100)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.set_option("profile", 1)
+    ds.set_option("max_sweeps", cap)
+    got = ds.optimize([a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=1,
+                      max_iter=1, seed=41)
+    prof, hits, longest = ds.profile(), int(ds.info("cap_hits")), int(ds.info("max_gene_sweeps"))
+    ds.close()
+    assert hits == 0 and 1024 < longest < cap, (hits, longest)          # deep solves, none stopped by the cap
+    assert ref["total_sweeps"] > 2000 * genes                            # thousands of sweeps per gene in this call
+    assert abs(prof["sweeps"] - ref["total_sweeps"]) <= 2 * genes, (prof["sweeps"], ref["total_sweeps"])   # +-1 per solve
+    assert got["iters"] == ref["iters"] == 2
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+    for i, a in enumerate(ref["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-6, i
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-6
+
+
 def test_c1_full_size_vs_oracle():
     """BASELINE config 1 (README.md:91-118 shapes): 377 x 5000, L = (2, 16, 8, 107), K = 23, lambda = 10, alpha = 0.4,
     fit()'s unmasked path (tuning = 0), 31 outer iterations, no sweep cap — the whole configuration against the oracle."""
@@ -141,6 +176,7 @@ def _full_size_properties(name, iters, compare_lists):
     got = ds.optimize([a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=1,
                       max_iter=iters - 1, seed=3)
     prof = ds.profile()
+    assert int(ds.info("cap_hits")) == 0, (name, ds.info("max_gene_sweeps"))   # no solve ended at the sweep cap
     if compare_lists:     # the per-entry list kernels give the same trajectory as whatever the cost models chose
         ds.set_option("row_merged", 0)
         ds.set_option("col_factored", 0)

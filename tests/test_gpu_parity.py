@@ -426,6 +426,7 @@ def test_c2_full_size_properties(c2):
     w = c2
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
     got = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=20, seed=3)
+    assert int(ds.info("cap_hits")) == 0, ds.info("max_gene_sweeps")   # no elastic-net solve ended at the sweep cap
     ds.close()
     tr = got["traj"]
     assert np.all(np.diff(tr[:, 7]) < 0)                      # checkpoint losses decrease
@@ -467,6 +468,7 @@ def test_c3_full_size_forms_agree_and_losses_recompute():
         for k, v in opts.items():
             ds.set_option(k, v)
         runs[name] = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=10, seed=3)
+        assert int(ds.info("cap_hits")) == 0, (name, ds.info("max_gene_sweeps"))   # the reference has no sweep cap: none may bite
         pr = ds.profile()
         assert pr["col_factored"] == (name != "lists") and pr["col_pair"] == (name == "pair")
     ds.close()
