@@ -137,7 +137,20 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
         c_oracle.set_col_chunk(100)
         c_oracle.set_cd_form(0)
     main = out["reference_threads"]
-    return {"value": main["value"], "unit": "outer-iterations/s", "cores": main["col_threads"], "kind": "port",
+    # the model (fixed cost per gene + cost per gene per sweep) against REAL oracle runs on a GPU box's host cores
+    # (tools/cpu_validate.py, one job per round): c2 in full, 31 iterations; a 4096-gene slab of c3, two iterations, uncapped
+    check = None
+    try:
+        mc = json.load(open(os.path.join(ROOT, "profiles", "r03", "cpu_model_check.json")))
+        check = {"source": "profiles/r03/cpu_model_check.json (tools/cpu_validate.py)", "cpu_model": mc.get("cpu_model"),
+                 "nproc": mc.get("nproc")}
+        for key in ("c2_full", "c3_slab"):
+            if key in mc:
+                check[key] = {k: mc[key][k] for k in ("shape", "iterations", "sweeps_per_gene_per_iter", "measured_wall_s",
+                                                      "model_wall_s", "measured_over_model") if k in mc[key]}
+    except Exception:
+        pass
+    return {"value": main["value"], "unit": "outer-iterations/s", "cores": main["col_threads"], "kind": "port", "model_check": check,
             "sample": (f"{name}: first {genes} of {cp} genes x all {cn} samples, 1 outer iteration, sweeps capped at {cap}, "
                        f"gene-loop chunk 1; {main['sample_wall_s']:.1f} s wall, cpu-time/wall {main['cpu_over_wall']:.1f} "
                        f"(row step {main['row_threads']} / column step {main['col_threads']} threads; the reference hard-codes "

@@ -381,9 +381,10 @@ struct RegWho {            // which gene a lane works for
 __device__ __forceinline__ RegWho reg_who(const ColArgs &a, int lane)
 {
     RegWho w;
-    const int row = lane >> 4, slot = blockIdx.x * 4 + row;
+    const int row = lane >> 4, slot = (a.slot_begin ? *a.slot_begin : 0) + blockIdx.x * 4 + row;
     w.i = lane & 15;
-    // a resumed pass (multi-pass solve) continues the genes the previous pass left unfinished: the first *pass_count of its order
+    // a resumed pass (multi-pass solve) continues the genes the previous pass left unfinished: the first *pass_count of its
+    // order; a split solve's long-gene launch takes the first n_long slots, its majority launch starts at slot n_long
     const int count = a.pass_count ? *a.pass_count : a.p;
     w.gene = slot < a.p && slot < count;
     const int sl = w.gene ? slot : 0;
@@ -420,14 +421,14 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
 {
     const int lane = threadIdx.x;
     const int K = a.K, KP = a.KP;
-    const bool resume = a.pass_count != nullptr;
+    const bool resume = a.resume != 0;
     __shared__ double stash[REG_STASH];
     double G[SLOTS][KMAX], beta[SLOTS], hs[SLOTS], is[SLOTS];
     bool unfinished = false, capped = false;
     int key = 0, sweeps = 0;
     {
         const RegWho w = reg_who(a, lane);
-        if (resume && __ballot(w.gene) == 0) return;
+        if (__ballot(w.gene) == 0) return;
         // start values first, the matrix afterwards: their inputs and the 2 x KMAX matrix registers are never live together
         RegState<SLOTS> S;
         {

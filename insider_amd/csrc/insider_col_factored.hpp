@@ -43,6 +43,12 @@ struct ColFacArgs {
     // block of 16 levels); static per data set (mask and levels only)
     const uint8_t *cnt;
     int cnt_stride, cnt_off[CF_MAXC], nsteps;   // bytes per gene, offset of position t, ceil(tab_rows / 4)
+    // split solves (k_col_paircnt): the long genes' records are formed first, from their list, so that their solve can start
+    // while the statistics of the others are still running; the launch over all genes then skips them
+    const int *list;                      // gene ids of this launch (null: all genes 0 .. p-1)
+    const int *list_count;                // ... of which the first *list_count are processed (null with list == null)
+    const uint16_t *skip_bkt;             // all-gene launch: skip gene j when skip_bkt[j] <= *skip_last (null: none)
+    const int *skip_last;
 };
 
 // Gc = M + M' for the lower blocks, XtX_j = R'R - Gc; qc and the sum of squares go into row KP - 1 of the record
@@ -214,8 +220,14 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
         tabs[i] = r < a.tab_rows ? a.Astack[(size_t)q * KP + k] : 0.0;
     }
     __syncthreads();
-    const int j = blockIdx.x * WPB + w;
-    if (j >= a.p) return;
+    int j = blockIdx.x * WPB + w;
+    if (a.list) {
+        if (j >= *a.list_count) return;
+        j = a.list[j];
+    } else {
+        if (j >= a.p) return;
+        if (a.skip_bkt && (int)a.skip_bkt[j] <= *a.skip_last) return;
+    }
     const int g4 = lane >> 4, c16 = lane & 15;
     double qh[NB];                       // the epilogue's operands, requested now
 #pragma unroll

@@ -168,6 +168,17 @@ struct insider_hip_handle {
     int *sched_cnt[2] = {nullptr, nullptr}, *sched_rank = nullptr;
     uint16_t *sched_bkt = nullptr;
     int sched_flip = 0;
+    // split column solves (steady-state outer iterations): the genes predicted longest — whole buckets of the launch order,
+    // at most cd_long_frac of the genes — get their statistics and their solve on a stream of their own, ahead of everyone
+    // else's statistics: the solve of the longest gene is the critical path of the column step (a sequential recurrence of
+    // sweeps x K steps x ~44 ns), and it no longer waits for the statistics of the other genes
+    int *sched_long = nullptr;        // device: {n_long, last long bucket} of the current gene_perm (k_sched_scatter)
+    bool sched_long_valid = false;
+    int cd_split = 1;                 // option "cd_split"
+    double cd_long_frac = 0.03;       // option "cd_long_frac"
+    hipStream_t lng = nullptr;
+    hipEvent_t ev_long_go = nullptr, ev_long_done = nullptr;
+    bool long_pending = false;
     // multi-pass column solves in the cold outer iterations (CdParams::sweep_limit): saved state of the unfinished genes,
     // their estimated remaining lengths (two buffers, alternating between passes) and the order of the next pass
     double *cd_hsave = nullptr, *cd_isave = nullptr;
@@ -217,12 +228,13 @@ void free_workspace(insider_hip_handle *h)
     if (h->order) (void)hipFree(h->order);
     h->order = nullptr;
     h->order_rows = 0;
-    for (void *q : {(void *)h->gene_perm, (void *)h->sched_cnt[0], (void *)h->sched_cnt[1], (void *)h->sched_rank, (void *)h->sched_bkt, (void *)h->cd_hsave,
+    for (void *q : {(void *)h->gene_perm, (void *)h->sched_cnt[0], (void *)h->sched_cnt[1], (void *)h->sched_rank, (void *)h->sched_bkt, (void *)h->sched_long, (void *)h->cd_hsave,
                     (void *)h->cd_isave, (void *)h->cd_pass_slot, (void *)h->cd_pass_perm[0], (void *)h->cd_pass_perm[1],
                     (void *)h->cd_pass_cnt})
         if (q) (void)hipFree(q);
-    h->gene_perm = h->sched_cnt[0] = h->sched_cnt[1] = h->sched_rank = nullptr;
+    h->gene_perm = h->sched_cnt[0] = h->sched_cnt[1] = h->sched_rank = h->sched_long = nullptr;
     h->sched_bkt = nullptr;
+    h->sched_long_valid = false;
     h->cd_hsave = h->cd_isave = nullptr;
     h->cd_pass_slot = nullptr;
     h->cd_pass_perm[0] = h->cd_pass_perm[1] = h->cd_pass_cnt = nullptr;
@@ -298,6 +310,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->sched_cnt[1], (size_t)SCHED_BUCKETS))) return rc;
     if ((rc = dmalloc(&h->sched_rank, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sched_bkt, (size_t)h->p))) return rc;
+    if ((rc = dmalloc(&h->sched_long, 2))) return rc;
     if ((rc = dmalloc(&h->sweep_key, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->cd_hsave, (size_t)h->p * KP))) return rc;
     if ((rc = dmalloc(&h->cd_isave, (size_t)h->p * KP))) return rc;
@@ -309,7 +322,9 @@ int ensure_workspace(insider_hip_handle *h, int K)
         if ((rc = dmalloc(&h->perm_early[e], (size_t)h->p))) return rc;
     HIPCHECK(hipMemsetAsync(h->sched_cnt[0], 0, SCHED_BUCKETS * sizeof(int), h->stream));
     HIPCHECK(hipMemsetAsync(h->sched_cnt[1], 0, SCHED_BUCKETS * sizeof(int), h->stream));
+    HIPCHECK(hipMemsetAsync(h->sched_long, 0, 2 * sizeof(int), h->stream));
     h->sched_flip = 0;
+    h->sched_long_valid = false;
     h->have_perm = false;
     // rows of the padded factor buffers beyond K must stay zero: C rows are gathered with pitch KP and the
     // pad genes of the transposed layout index rows p..ldp-1
@@ -450,6 +465,13 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     return INSIDER_OK;
 }
 
+// most genes a split solve treats as long (whole buckets of the launch order up to this many)
+int long_cap(const insider_hip_handle *h)
+{
+    const double f = h->cd_long_frac < 0.0 ? 0.0 : (h->cd_long_frac > 0.25 ? 0.25 : h->cd_long_frac);
+    return (int)(f * (double)h->p);
+}
+
 // the launch order of the next column solve: genes by decreasing key, a bucket sort on a log scale (insider_kernels.hpp).
 // sweeps != null: the keys are first updated from the last solve's sweep counts (reset: replaced, else smoothed)
 int launch_gene_order(insider_hip_handle *h, const int *sweeps, int reset, int float_bits, hipStream_t st)
@@ -460,8 +482,10 @@ int launch_gene_order(insider_hip_handle *h, const int *sweeps, int reset, int f
                        h->sweep_key, cnt, h->sched_bkt, h->sched_rank);
     KCHECK();
     hipLaunchKernelGGL(k_sched_scatter, dim3(cdiv(h->p, 256)), dim3(256), 0, st, (const int *)cnt, cnt_next,
-                       (const uint16_t *)h->sched_bkt, (const int *)h->sched_rank, (int)h->p, h->gene_perm);
+                       (const uint16_t *)h->sched_bkt, (const int *)h->sched_rank, (int)h->p, h->gene_perm, long_cap(h),
+                       h->sched_long);
     KCHECK();
+    h->sched_long_valid = !float_bits;   // the sum-of-squares order of a first solve predicts no lengths
     return INSIDER_OK;
 }
 
@@ -496,8 +520,20 @@ int col_stats_path(const insider_hip_handle *h)
 }
 bool use_col_factored(const insider_hip_handle *h) { return col_stats_path(h) != 0; }
 
+// Should this outer iteration's column step run split (long genes on their own stream, ahead of the others' statistics)?
+// Steady-state iterations only (the cold ones are throughput-bound and solve in passes), the pair-count statistics, the
+// register-resident sweep kernel, and a launch order made from sweep counts.
+bool use_split(const insider_hip_handle *h, int masked, double alpha, int outer_iter)
+{
+    return h->cd_split && masked && alpha != 0.0 && h->cd_variant == 0 && h->K <= 32 && col_stats_path(h) == 2 &&
+           outer_iter >= std::max(h->cd_cold_iters, (int)insider_hip_handle::EARLY) && h->have_perm && h->sched_long_valid &&
+           long_cap(h) >= 4;
+}
+
 // masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
-int launch_col_stats(insider_hip_handle *h, bool timed)
+// split: the long genes' records first, on the stream `lng` (their solve follows there, launch_col_solve); the launch over
+// all genes on the main stream skips them
+int launch_col_stats(insider_hip_handle *h, bool timed, bool split = false)
 {
     Timer t;
     int rc = t.begin(h, timed);
@@ -514,6 +550,26 @@ int launch_col_stats(insider_hip_handle *h, bool timed)
         a.stat = h->stat_col;
         if (col_stats_path(h) == 2) {
             a.cnt = h->cf_cnt;
+            if (split) {
+                // the long branch starts here: everything the main stream has produced so far (row factors, R'R, Qheld)
+                // plus what the side stream prepares for the solve (launch order, sweep-order table, Qfull)
+                HIPCHECK(hipEventRecord(h->ev_long_go, h->stream));
+                HIPCHECK(hipStreamWaitEvent(h->lng, h->ev_long_go, 0));
+                if (h->side_pending) HIPCHECK(hipStreamWaitEvent(h->lng, h->ev_side_done, 0));
+                if (h->qfull_pending) HIPCHECK(hipStreamWaitEvent(h->lng, h->ev_qfull, 0));
+                ColFacArgs al = a;
+                al.list = h->gene_perm;
+                al.list_count = h->sched_long;
+                NB_DISPATCH(h->NB, {
+                    (void)WPB_;
+                    const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
+                    hipLaunchKernelGGL((k_col_paircnt<NB_, 4>), dim3(cdiv(long_cap(h), 4)), dim3(256), lds, h->lng, al);
+                });
+                KCHECK();
+                h->long_pending = true;
+                a.skip_bkt = h->sched_bkt;
+                a.skip_last = h->sched_long + 1;
+            }
             NB_DISPATCH(h->NB, {
                 (void)WPB_;
                 const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
@@ -625,6 +681,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.hsave = h->cd_hsave;
         a.isave = h->cd_isave;
         a.pass_count = nullptr;
+        a.slot_begin = nullptr;
+        a.resume = 0;
         a.pass_slot = nullptr;
         a.bucket_cnt = nullptr;
         a.cap_hits = solve ? h->failflag + 2 : nullptr;
@@ -642,6 +700,18 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
                     limits[npass++] = (int)l;
             int start = 0;
             const int *perm_in = a.gene_perm;
+            if (h->long_pending) {
+                // split solve: the long genes (the first n_long slots of the launch order) on their own stream, right after their
+                // statistics; everyone else here, from slot n_long on
+                ColArgs al = a;
+                al.cd.start_sweep = 0;
+                al.cd.sweep_limit = 0;
+                al.pass_count = h->sched_long;
+                REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, true>), dim3(cdiv(long_cap(h), 4)), dim3(64), 0, h->lng, al));
+                KCHECK();
+                HIPCHECK(hipEventRecord(h->ev_long_done, h->lng));
+                a.slot_begin = h->sched_long;
+            }
             for (int pass = 0;; ++pass) {
                 const int limit = pass < npass ? limits[pass] : 0;
                 a.cd.start_sweep = start;
@@ -659,7 +729,12 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
                 KCHECK();
                 perm_in = a.gene_perm = h->cd_pass_perm[pass & 1];
                 a.pass_count = count_out;
+                a.resume = 1;
                 start = limit;
+            }
+            if (h->long_pending) {   // the column step ends when both parts have
+                HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_long_done, 0));
+                h->long_pending = false;
             }
             eval_after = checkpoint != 0;
             eval_args = a;
@@ -676,6 +751,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
     if (eval_after) {   // the per-gene loss statistics of the (updated) columns: the evaluation kernel, all genes (not part of the solve's time)
         eval_args.gene_perm = nullptr;
         eval_args.pass_count = nullptr;
+        eval_args.slot_begin = nullptr;
+        eval_args.resume = 0;
         REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, false>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, eval_args));
         KCHECK();
     }
@@ -1113,6 +1190,9 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
     if (h->side3) (void)hipStreamDestroy(h->side3);
+    if (h->lng) (void)hipStreamDestroy(h->lng);
+    if (h->ev_long_go) (void)hipEventDestroy(h->ev_long_go);
+    if (h->ev_long_done) (void)hipEventDestroy(h->ev_long_done);
     if (h->ev_prep) (void)hipEventDestroy(h->ev_prep);
     if (h->ev_c_ready) (void)hipEventDestroy(h->ev_c_ready);
     if (h->ev_a_ready) (void)hipEventDestroy(h->ev_a_ready);
@@ -1175,6 +1255,9 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     CH(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     CH(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     CH(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
+    CH(hipStreamCreateWithFlags(&h->lng, hipStreamNonBlocking));
+    CH(hipEventCreateWithFlags(&h->ev_long_go, hipEventDisableTiming));
+    CH(hipEventCreateWithFlags(&h->ev_long_done, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_a_ready, hipEventDisableTiming));
@@ -1555,6 +1638,8 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
+    else if (s == "cd_split") h->cd_split = (int)value;           // 1 (default) = steady-state column steps run split: long genes first, on their own stream
+    else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
@@ -1572,12 +1657,14 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     HIPCHECK(hipStreamSynchronize(h->side));
     HIPCHECK(hipStreamSynchronize(h->side2));
     HIPCHECK(hipStreamSynchronize(h->side3));
+    HIPCHECK(hipStreamSynchronize(h->lng));
     if ((rc = ensure_workspace(h, K))) return rc;
     const auto t_begin = std::chrono::steady_clock::now();
     clear_events(h);
     h->w_ready = false;
     h->side_pending = false;
     h->qfull_pending = false;
+    h->long_pending = false;
     const int masked = tuning == 1;
     if ((rc = upload_factors(h, A, C, K))) return rc;
 
@@ -1633,7 +1720,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
         const int checkpoint = iter % 10 == 0;
         if (alpha != 0.0 && iter == 0)   // later iterations: prepared on the side stream right after the previous solve
             if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
-        if (masked) if ((rc = launch_col_stats(h, true))) return rc;
+        if (masked) if ((rc = launch_col_stats(h, true, use_split(h, masked, alpha, (int)iter)))) return rc;
         if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true, (int)iter, true))) return rc;  // :376
         if (alpha != 0.0) {
             if (iter < max_iter)
@@ -1733,7 +1820,8 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         (void)hipStreamSynchronize(h->side);
         (void)hipStreamSynchronize(h->side2);
         (void)hipStreamSynchronize(h->side3);
-        h->side_pending = h->qfull_pending = h->w_ready = false;
+        (void)hipStreamSynchronize(h->lng);
+        h->side_pending = h->qfull_pending = h->w_ready = h->long_pending = false;
         if (h->failflag) (void)hipMemset(h->failflag, 0, 4 * sizeof(int));
         clear_events(h);
         g_err = keep;

@@ -658,7 +658,10 @@ struct ColArgs {
     const int *gene_perm;    // launch slot -> gene (genes sorted by their last sweep count, longest first), or null
     // multi-pass solves (CdParams::sweep_limit / start_sweep)
     double *hsave, *isave;       // p x KP each: h and 1/D-or-0 of the genes a limited pass left unfinished
-    const int *pass_count;       // resumed pass: number of genes to continue = the first *pass_count entries of gene_perm; else null
+    const int *pass_count;       // launch covers the slots below *pass_count only (null: all p): a resumed pass continues the first
+                                 // *pass_count entries of its order; the long-gene launch of a split solve takes the first n_long
+    const int *slot_begin;       // first slot of the launch = *slot_begin (null: 0): the majority launch of a split solve starts at n_long
+    int resume;                  // the launch continues solves that a limited pass stopped (state in hsave / isave)
     uint32_t *pass_slot;         // limited pass, per gene it processed: CD_PASS_DONE, or (bucket << 24 | rank in the bucket) of a gene it
                                  // leaves unfinished (bucket = its estimated remaining sweeps on a log scale, see k_pass_scatter)
     int *bucket_cnt;             // limited pass: CD_BUCKETS counters (zeroed by the host)
@@ -978,10 +981,13 @@ __global__ void __launch_bounds__(256) k_sched_bucket(const int *__restrict__ sw
 }
 
 // perm[start of the gene's bucket + its rank] = gene; every block forms the bucket starts itself (exclusive scan of the
-// SCHED_BUCKETS counters in LDS).  Block 0 also clears cnt_next, the counters of the next use (two sets alternate).
+// SCHED_BUCKETS counters in LDS).  Block 0 also clears cnt_next, the counters of the next use (two sets alternate), and
+// picks the LONG genes of a split solve: whole buckets from the longest down while they number at most cap_long — a set that
+// does not depend on the order of the atomics.  long_out[0] = their number n_long (they are perm[0 .. n_long)), long_out[1] =
+// the last long bucket (-1: none).
 __global__ void __launch_bounds__(256) k_sched_scatter(const int *__restrict__ cnt, int *__restrict__ cnt_next,
                                                        const uint16_t *__restrict__ bkt, const int *__restrict__ rank, int p,
-                                                       int *__restrict__ perm)
+                                                       int *__restrict__ perm, int cap_long, int *__restrict__ long_out)
 {
     constexpr int PER = SCHED_BUCKETS / 256;
     __shared__ int off[SCHED_BUCKETS];
@@ -1002,8 +1008,28 @@ __global__ void __launch_bounds__(256) k_sched_scatter(const int *__restrict__ c
 #pragma unroll
     for (int q = 0; q < PER; ++q) off[t * PER + q] = base + loc[q];
     __syncthreads();
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (int q = t; q < SCHED_BUCKETS; q += 256) cnt_next[q] = 0;
+        // inclusive counts are non-decreasing in the bucket index: the last bucket whose inclusive count fits the cap
+        int best = -1;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int incl = base + loc[q] + cnt[t * PER + q];
+            if (incl <= cap_long && incl > 0) best = t * PER + q;
+        }
+        __syncthreads();
+        tot[t] = best;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (t < o) tot[t] = tot[t] > tot[t + o] ? tot[t] : tot[t + o];
+            __syncthreads();
+        }
+        if (t == 0 && long_out) {
+            const int b = tot[0];
+            long_out[0] = b >= 0 ? off[b] + cnt[b] : 0;
+            long_out[1] = b;
+        }
+    }
     const int j = blockIdx.x * 256 + t;
     if (j < p) perm[off[bkt[j]] + rank[j]] = j;
 }

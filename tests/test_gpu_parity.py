@@ -347,6 +347,37 @@ def test_multipass_column_solve_is_bit_identical(oracle, K, limits):
     assert abs(tot_multi - ref["total_sweeps"]) <= max(3, 0.002 * ref["total_sweeps"])
 
 
+@pytest.mark.parametrize("K,frac", [(12, 0.03), (30, 0.1), (20, 0.25), (30, 0.001)])
+def test_split_column_step_is_bit_identical(oracle, K, frac):
+    """Steady-state outer iterations run the column step split (option cd_split, default on): the genes predicted longest —
+    whole buckets of the launch order, at most cd_long_frac of the genes — get their statistics and their solve on a stream of
+    their own, ahead of the statistics of everyone else.  Every gene's record and solve are the same computations as in the
+    unsplit step, so factors, trajectory and sweep counts must be bit-identical (and agree with the oracle)."""
+    w = workloads.small(K=K, n=150, p=1500, level_counts=(12, 5), f=0.2, seed=40 + K)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.set_option("profile", 1)
+    ds.set_option("col_factored", 3)            # the pair-count statistics (what c3 / c4 take): the split path's kernel
+    assert int(ds.info("col_stats_path")) == 2
+    kw = dict(tuning=1, max_iter=12, seed=9)
+    ds.set_option("cd_split", 0)
+    one = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, **kw)
+    sw_one, tot_one = ds.sweeps(), ds.profile()["sweeps"]
+    ds.set_option("cd_split", 1)
+    ds.set_option("cd_long_frac", frac)
+    two = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, **kw)
+    sw_two, tot_two = ds.sweeps(), ds.profile()["sweeps"]
+    ds.close()
+    assert np.array_equal(one["column_factor"], two["column_factor"])
+    assert np.array_equal(one["traj"], two["traj"], equal_nan=True)
+    for i in range(len(w.A0)):
+        assert np.array_equal(one["row_matrices"][f"factor{i}"], two["row_matrices"][f"factor{i}"])
+    assert np.array_equal(sw_one, sw_two) and tot_one == tot_two
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                          max_iter=12, seed=9)
+    assert relerr(two["column_factor"], ref["column_factor"]) < 1e-6
+    np.testing.assert_allclose(two["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+
+
 def test_sweep_counts_match_oracle(oracle):
     w = workloads.small(K=12, n=80, p=64)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
