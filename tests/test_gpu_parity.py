@@ -362,7 +362,7 @@ def test_split_column_step_is_bit_identical(oracle, K, frac):
     ds.set_option("cd_split", 0)
     one = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, **kw)
     sw_one, tot_one = ds.sweeps(), ds.profile()["sweeps"]
-    ds.set_option("cd_split", 1)
+    ds.set_option("cd_split", 2)                # forced (the default engages it by problem size)
     ds.set_option("cd_long_frac", frac)
     two = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, **kw)
     sw_two, tot_two = ds.sweeps(), ds.profile()["sweeps"]
