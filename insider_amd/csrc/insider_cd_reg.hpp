@@ -10,7 +10,7 @@
 // one per coordinate, whose byte offsets the order table holds per sweep position (34 dwords loaded into SGPRs at
 // the start of a sweep, indexed with s_movrels).  Inside block k everything is static — the Gram operand is the register holding G[u][k], the lane that
 // owns k is k % 16, and its (negated) increment reaches the row as the DPP row_newbcast:k%16 source operand of a
-// 64-bit v_fmac_f64 (gfx90a+ "DP ALU DPP").  Per step and wave (4 genes): 7 vector + 5 scalar instructions, no
+// 64-bit v_fmac_f64 (gfx90a+ "DP ALU DPP").  Per step and wave (4 genes): 7 vector + 4 scalar instructions, no
 // memory or LDS access; the sweep is one inline-asm block (the compiler turns a C++ switch into a compare tree with
 // register copies at the merge).  Without LDS the occupancy is set by registers alone (REG_WAVES(KMAX) waves per
 // SIMD), where the LDS-resident variant (insider_cd_row16.hpp) held 5 waves per CU at K = 30.
@@ -31,7 +31,7 @@ struct RegState {
 
 // ---- the sweep as one asm block -----------------------------------------------------------------------------------
 // Block for coordinate KK (slot s = KK / 16, owner lane it = KK % 16), src/coordinate_descent.cpp:91-110 in covariance
-// form: x = soft(h_s, la); dn = beta_s - x inv_s (one fma: minus the increment); beta_s[it] -= dn;
+// form, on the owner lanes: x = soft(h_s, la); dn = beta_s - x inv_s (one fma: minus the increment); beta_s -= dn; on all lanes:
 // h_u += bcast_it(dn) * G_u[KK].  soft(h, la) = h - clamp(h, -la, la); x = 0 gives dn = beta_s and beta_s[it] = 0 exactly.  Screened-out coordinates and parked genes carry inv = beta = 0, i.e. a zero increment.
 // The sweep's order arrives as a successor list of code-block offsets (k_order_table: dword 0 = first block, dword 1 + k
 // = the block visited after coordinate k, the exit block after the last), loaded into s[64:97] at the start of the sweep
@@ -42,7 +42,10 @@ struct RegState {
 // position counter, M0 untouched.  Critical chain per step: min, max, add, fma (dn), DPP fmac.  Hazards respected by
 // construction: >= 2 instructions between the write of dn and its DPP read; exec is written by SALU only; nothing in a
 // block writes vcc_hi.
-#if defined(INSIDER_REG_EXEC_HEAD)   // experiment (tools/ab_variants.sh): the five scalar-like instructions of a step on the owner lanes only
+// The five scalar-like instructions of a step (soft threshold, increment, beta update) do useful work on the owner lane of each
+// row only: they run under a four-lane exec mask (the DPP fmacs that follow need every lane).  Same instruction count as
+// narrowing the mask around the beta update alone, but the part sustains a higher clock: 200.5 -> 208.6 G coordinate updates/s
+// at c3 (round 3, tools/ab_variants.sh), bit-identical results.
 #define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
     ".org Lc%= + 96*" #KK "\n"                                   \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
@@ -53,18 +56,6 @@ struct RegState {
     "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
     "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
     "s_mov_b64 exec, -1\n"
-#else
-#define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
-    ".org Lc%= + 96*" #KK "\n"                                   \
-    "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
-    "v_min_f64 %[c], %[" HS "], %[la]\n"                         \
-    "v_max_f64 %[c], %[c], -%[la]\n"                             \
-    "v_add_f64 %[c], %[" HS "], -%[c]\n"                         \
-    "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
-    "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
-    "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
-    "s_mov_b64 exec, -1\n"
-#endif
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
 #define REG_BLOCK2_LO(KK) \
     REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) "s_setpc_b64 vcc\n"

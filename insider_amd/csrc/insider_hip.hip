@@ -521,6 +521,18 @@ int col_stats_path(const insider_hip_handle *h)
 }
 bool use_col_factored(const insider_hip_handle *h) { return col_stats_path(h) != 0; }
 
+// the pair-count statistics kernel (insider_col_factored.hpp) on `blocks` blocks of four genes
+int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipStream_t st)
+{
+    NB_DISPATCH(h->NB, {
+        (void)WPB_;
+        const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
+        hipLaunchKernelGGL((k_col_paircnt<NB_, 4>), dim3(blocks), dim3(256), lds, st, a);
+    });
+    KCHECK();
+    return INSIDER_OK;
+}
+
 // Should this outer iteration's column step run split (long genes on their own stream, ahead of the others' statistics)?
 // Steady-state iterations only (the cold ones are throughput-bound and solve in passes), the pair-count statistics, the
 // register-resident sweep kernel, and a launch order made from sweep counts.
@@ -531,11 +543,13 @@ bool use_split(const insider_hip_handle *h, int masked, double alpha, int outer_
           long_cap(h) >= 4))
         return false;
     if (h->cd_split >= 2) return true;   // forced
-    // Worth it when the solve is bound by its longest gene, i.e. when the genes fill the GPU's wave slots only a few times
-    // over (measured: a 25000-gene slab of c4 gains 13 % per steady iteration; at c3's 50000 genes the solve is
-    // throughput-bound, and the long genes' sweeps next to the others' MFMA-bound statistics cost more than their head start)
+    // Worth it when the solve is bound by its longest gene AND the statistics are a sizeable head start.  Measured (round 3):
+    // a 25000-gene slab of c4 (one rank of the 8-GPU configuration) 1.36 -> 1.18 ms per steady iteration; c3's 50000 genes on
+    // one GPU are throughput-bound and lose 2 % (the long genes' sweeps next to the others' MFMA-bound statistics cost more
+    // than the head start); c2 (20000 genes, statistics 0.1 of 1.3 ms) loses 3 %.  Default: gene-sharded handles whose slab
+    // fills the GPU's wave slots at most three times over.
     const int64_t slots = (int64_t)h->n_simd * reg_waves(reg_kmax(h->K)) * 4;
-    return h->p <= 3 * slots;
+    return h->world > 1 && h->p <= 3 * slots;
 }
 
 // masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
@@ -568,21 +582,15 @@ int launch_col_stats(insider_hip_handle *h, bool timed, bool split = false)
                 ColFacArgs al = a;
                 al.list = h->gene_perm;
                 al.list_count = h->sched_long;
-                NB_DISPATCH(h->NB, {
-                    (void)WPB_;
-                    const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
-                    hipLaunchKernelGGL((k_col_paircnt<NB_, 4>), dim3(cdiv(long_cap(h), 4)), dim3(256), lds, h->lng, al);
-                });
+                rc = launch_paircnt(h, al, cdiv(long_cap(h), 4), h->lng);
+                if (rc) return rc;
                 KCHECK();
                 h->long_pending = true;
                 a.skip_bkt = h->sched_bkt;
                 a.skip_last = h->sched_long + 1;
             }
-            NB_DISPATCH(h->NB, {
-                (void)WPB_;
-                const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
-                hipLaunchKernelGGL((k_col_paircnt<NB_, 4>), dim3(cdiv(h->p, 4)), dim3(256), lds, h->stream, a);
-            });
+            rc = launch_paircnt(h, a, cdiv(h->p, 4), h->stream);
+            if (rc) return rc;
         } else {
             NB_DISPATCH(h->NB, {
                 (void)WPB_;
@@ -1650,7 +1658,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
-    else if (s == "cd_split") h->cd_split = (int)value;           // steady-state column steps run split (long genes first, on their own stream): 1 (default) = when the genes fill the wave slots at most 3 times, 2 = always, 0 = never
+    else if (s == "cd_split") h->cd_split = (int)value;           // steady-state column steps run split (long genes first, on their own stream): 1 (default) = gene-sharded handles whose slab fills the wave slots at most 3 times, 2 = always, 0 = never
     else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
