@@ -16,6 +16,17 @@ import bench
 from insider_amd import workloads
 from oracle import c_oracle
 
+import threading
+_t0 = time.time()
+
+
+def _heartbeat():      # the GPU box kills a job that prints nothing for seven minutes; the oracle runs are silent for longer
+    while True:
+        time.sleep(60)
+        print(f"[cpu_validate] still running, {time.time() - _t0:.0f} s", flush=True)
+
+
+threading.Thread(target=_heartbeat, daemon=True).start()
 out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03", "cpu_model_check.json")
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 c_oracle.build()
