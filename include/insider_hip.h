@@ -103,7 +103,10 @@ int insider_hip_set_shard(insider_hip_handle *h, int64_t gene_offset, int rank, 
 int insider_hip_comm_unique_id(void *out, int out_bytes);
 int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank, int world);
 
-/* Options: "max_sweeps" (per elastic-net subproblem, default 10000), "order_mode" (0 = hashed random order of
+/* Options: "max_sweeps" (safety cap on the sweeps of one elastic-net subproblem, default 2^24: the reference's loop has none,
+ * src/coordinate_descent.cpp:86-114, and neither does this library in practice — the sweep-order table holds one period of
+ * the order sequence, INSIDER_PERM_PERIOD = 16384 rows, whatever the cap; insider_hip_get_info("cap_hits") counts the solves
+ * of the last call that the cap ended), "order_mode" (0 = hashed random order of
  * include/insider_perm.h, 1 = cyclic), "profile" (1 = time the statistics / solve kernels with HIP events),
  * "verbose" (1 = print the reference's per-checkpoint lines to stdout), "cd_variant" (elastic-net sweep kernel for
  * K <= 32: 0 = four genes per wavefront with the Gram matrix in registers, 2 = four genes per wavefront with the Gram
@@ -113,7 +116,11 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * entry, 2 = per-(covariate, level) terms with one table look-up per entry, 3 = per-(covariate, level) terms from the
  * gene's dense level-pair counts [falls back to 2 when a count exceeds one byte]; same results), "row_counts" (1, default = the merged row update takes its per-gene level sums from the dense
  * level-pair counts when they exist, 0 = from the entry lists; same results), "force_allreduce" (1 = call the all-reduce callback even
- * when world == 1: plumbing rehearsal), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
+ * when world == 1: plumbing rehearsal), "cd_split" / "cd_long_frac" (steady-state column steps run split: the genes predicted longest — whole buckets of the
+ * launch order, at most cd_long_frac [0.03] of the genes — get their statistics and their solve on a stream of their own, ahead
+ * of the others' statistics; 1 [default] = on gene-sharded handles whose slab fills the GPU's wave slots at most three times, 2 =
+ * always, 0 = never; bit-identical results), "row_fused" (1, default = the merged row update forms a level's equations and
+ * solve in one launch), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
  * cd_cold_iters outer iterations of a call [default 3]: the register-resident sweep kernel stops at sweep cd_pass1 [64; 0 = one
  * pass], cd_pass1 x ratio [4], ..., re-packing the genes still running by their estimated remaining length between passes;
  * the iterates are bit-identical to the single-pass solve). */
@@ -234,7 +241,9 @@ int insider_hip_get_profile(insider_hip_handle *h, double *out12);
  * (v_mfma_f64_16x16x4 instructions the column-side statistics kernel issues per gene), "row_merged", "col_entries",
  * "row_entries" (padded held-out list lengths), "lists_bytes", "pair_count_bytes_per_gene", "stat_doubles", "kp",
  * "cd_ms_steady" / "col_stats_ms_steady" (option "profile": mean HIP-event time per outer iteration from iteration 5 on of
- * the last optimize(), i.e. without the cold start). */
+ * the last optimize(), i.e. without the cold start), "cap_hits" / "max_gene_sweeps" (of the last optimize() / optimize_col():
+ * elastic-net solves ended by "max_sweeps" instead of convergence — must be 0 to match the reference, which has no cap — and
+ * the longest solve in sweeps), "max_sweeps". */
 int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out);
 
 /* Diagnostics: copy an internal per-gene array to the host: "cd_pass_slot" (uint32 x p: what the last limited pass of a

@@ -45,9 +45,16 @@ INSIDER_HD uint32_t insider_h32(uint32_t x)
     return x;
 }
 
+/* The order sequence of one solve repeats after INSIDER_PERM_PERIOD sweeps (a power of two): sweep s takes the order of
+ * sweep s mod PERIOD.  A solve that long has seen 16384 fresh uniformly random orders; what the period buys is a
+ * sweep-order table of fixed size on the device (PERIOD rows per outer iteration), so that the number of sweeps of a solve
+ * needs no cap — the reference's loop has none (src/coordinate_descent.cpp:86-114). */
+#define INSIDER_PERM_PERIOD 16384u
+
 /* Per-(seed, iteration, sweep) base word; uniform across coordinates and genes. */
 INSIDER_HD uint32_t insider_perm_base(uint64_t seed, uint32_t iter, uint32_t sweep)
 {
+    sweep &= INSIDER_PERM_PERIOD - 1U;
     uint32_t b = insider_h32((uint32_t)seed ^ 0x9E3779B9U);
     b = insider_h32(b ^ (uint32_t)(seed >> 32) ^ (0x85EBCA6BU * iter));
     b = insider_h32(b + 0xC2B2AE35U * sweep);

@@ -264,7 +264,7 @@ def optimize(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, 
 
 
 def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX=None, Xty=None, tol=1e-5, seed=DEFAULT_SEED, it=0,
-                              order_mode=0, max_sweeps=10000, device=0, return_sweeps=False):
+                              order_mode=0, max_sweeps=1 << 24, device=0, return_sweeps=False):
     """strong_coordinate_descent() of R/RcppExports.R:8-10 (src/coordinate_descent.cpp:56-127).
 
     Single problem (the reference's signature): ``X`` m x K, ``y`` m; ``XtX`` / ``Xty`` are formed on the device as X'X

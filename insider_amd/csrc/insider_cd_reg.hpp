@@ -285,12 +285,14 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(sweep), "+s"(stop));
 #endif
-    const uint32_t *tb = reinterpret_cast<const uint32_t *>(order + (size_t)sweep * ORDER_ROW + REG_ORDER_OFF);
+    // the table holds one period of the order sequence: sweep s reads row s mod INSIDER_PERM_PERIOD (include/insider_perm.h)
+    const uint32_t *tb0 = reinterpret_cast<const uint32_t *>(order + REG_ORDER_OFF);
+    const uint32_t *tb = tb0 + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * (ORDER_ROW / 4);
     while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
         reg_sweep(S, G, la, tb);
-        tb += ORDER_ROW / 4;
         ++sweep;
+        tb = (sweep & (int)(INSIDER_PERM_PERIOD - 1)) ? tb + ORDER_ROW / 4 : tb0;
         // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
         double acc = 0.0, acc1 = 0.0;
 #pragma unroll

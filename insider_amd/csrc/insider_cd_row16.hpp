@@ -169,13 +169,13 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
 
     while (__any(run)) {
         // ---- this sweep's order: scalar copy for the row offsets, per-lane ids (prefetched) for the columns -----
-        const uint32_t *orow = reinterpret_cast<const uint32_t *>(P.order + (size_t)sweep * ORDER_ROW + 64);
+        const uint32_t *orow = reinterpret_cast<const uint32_t *>(P.order + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * ORDER_ROW + 64);
         uint32_t ordw[8 * SLOTS];
 #pragma unroll
         for (int w = 0; w < 8 * SLOTS; ++w) ordw[w] = __builtin_amdgcn_readfirstlane((int)orow[w]);
         int nn[SLOTS];
         {
-            const size_t nx = (size_t)(sweep + 1 < P.max_sweeps ? sweep + 1 : sweep) * ORDER_ROW;
+            const size_t nx = (size_t)((sweep + 1 < P.max_sweeps ? sweep + 1 : sweep) & (int)(INSIDER_PERM_PERIOD - 1)) * ORDER_ROW;
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) nn[u] = 16 * u + i < K ? (int)P.order[nx + 16 * u + i] : 0;
         }

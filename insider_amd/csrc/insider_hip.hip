@@ -155,6 +155,7 @@ struct insider_hip_handle {
     int max_items = 0;
     bool merged = false;              // the merged masked row update is available (categorical covariates only)
     int row_merged = 1;               // option: use it
+    int row_fused = 1;                // option "row_fused": level records' tail + equations + solve of the merged update in one launch
     double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
     int *sweeps = nullptr, *failflag = nullptr;
     int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sched_bucket)
@@ -201,7 +202,7 @@ struct insider_hip_handle {
     void *allreduce_user = nullptr;
     ncclComm_t comm = nullptr;     // RCCL communicator over the gene-sharded ranks (insider_hip_comm_init); owned
     // options
-    int max_sweeps = 10000, order_mode = 0, profile = 0, verbose = 0, cd_variant = 0, force_allreduce = 0;
+    int max_sweeps = 1 << 24, order_mode = 0, profile = 0, verbose = 0, cd_variant = 0, force_allreduce = 0;
     // profile of the last optimize()
     std::vector<hipEvent_t> ev_col, ev_row, ev_cd, ev_test;
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -453,15 +454,17 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
                        hipStream_t stream = nullptr)
 {
     if (!stream) stream = h->stream;
-    if (h->order_rows < max_sweeps) {
+    // one period of the order sequence at most (include/insider_perm.h): the table does not grow with max_sweeps
+    const int rows = std::min<int64_t>(max_sweeps, INSIDER_PERM_PERIOD);
+    if (h->order_rows < rows) {
         if (h->order) (void)hipFree(h->order);
         h->order = nullptr;
-        int rc = dmalloc(&h->order, (size_t)(max_sweeps + 1) * ORDER_ROW);   // + one row: the CD kernel prefetches ahead
+        int rc = dmalloc(&h->order, (size_t)(rows + 4) * ORDER_ROW);   // + the look-ahead row (and the prologue's touch of the one after)
         if (rc) return rc;
-        h->order_rows = max_sweeps;
+        h->order_rows = rows;
     }
-    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)max_sweeps * 64, 256)), dim3(256), 0, stream, seed, iter, K,
-                       max_sweeps, order_mode, K * 8, reg_kmax(K), h->order);
+    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)(rows + 1) * 64, 256)), dim3(256), 0, stream, seed, iter, K, rows,
+                       order_mode, K * 8, reg_kmax(K), h->order);
     KCHECK();
     return INSIDER_OK;
 }
@@ -712,8 +715,9 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
             // bit-identically in waves of similar length (insider_cd_reg.hpp).  A pass with nothing left exits at once.
             int limits[16], npass = 0;
             if (solve && outer_iter >= 0 && outer_iter < h->cd_cold_iters && h->cd_pass_first >= 32)
-                for (int64_t l = h->cd_pass_first; l < h->max_sweeps && npass < 16; l *= std::max(h->cd_pass_ratio, 2))
-                    limits[npass++] = (int)l;
+                for (int64_t l = h->cd_pass_first; l < std::min<int64_t>(h->max_sweeps, 4 * (int64_t)INSIDER_PERM_PERIOD) && npass < 16;
+                     l *= std::max(h->cd_pass_ratio, 2))
+                    limits[npass++] = (int)l;   // the last pass runs from the last limit to the end, however far that is
             int start = 0;
             const int *perm_in = a.gene_perm;
             if (h->long_pending) {
@@ -914,9 +918,10 @@ int launch_wsyrk_side(insider_hip_handle *h)
 
 // one covariate's row update: categorical covariate i (optimize_row, src/optimize.cpp:139-198), or continuous
 // column j (optimize_continuous_v2, :76-137) when cont_col >= 0
-int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double lambda1)
+int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double lambda1, bool rebuild_R = true)
 {
     const bool cont = cont_col >= 0;
+    bool fused_solve = false;
     const CovTables &ct = cont ? h->cont : h->cov[i];
     const int row0 = cont ? h->SLcat + cont_col : h->lvl_off[i];   // first row of this covariate in Astack / SC
     LevelArgs la;
@@ -979,11 +984,21 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
                 hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), L), dim3(256), 0, h->stream, (const double *)h->wpart,
                                    (const int *)ct.lvl_item_ptr, STAT_, rec, PLEN);
             }
-            hipLaunchKernelGGL(k_level_pack, dim3(L), dim3(256), 0, h->stream, (const double *)h->Ylvl,
-                               (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
-                               (const int *)(h->lvl_count_all + h->lvl_off[i]), L, h->K, KP, STAT_, rec);
-            ra.part = rec;
-            hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(L), dim3(64), 0, h->stream, ra);
+            // the level records' tail, the level equations and (unless the equations still have to cross ranks) the solves: one launch
+            fused_solve = h->world <= 1 && !h->force_allreduce && h->row_fused && NB_ <= 2;
+            if (h->row_fused)
+                hipLaunchKernelGGL((k_level_merged<NB_>), dim3(L), dim3(256), 0, h->stream, (const double *)rec,
+                                   (const double *)h->Ylvl, (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
+                                   (const int *)(h->lvl_count_all + h->lvl_off[i]), (const double *)h->CCt,
+                                   (const double *)(h->SC + (size_t)row0 * KP), L, h->K, lambda1, fused_solve ? 1 : 0, h->eq,
+                                   h->Astack + (size_t)row0 * KP, h->failflag);
+            else {
+                hipLaunchKernelGGL(k_level_pack, dim3(L), dim3(256), 0, h->stream, (const double *)h->Ylvl,
+                                   (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
+                                   (const int *)(h->lvl_count_all + h->lvl_off[i]), L, h->K, KP, STAT_, rec);
+                ra.part = rec;
+                hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(L), dim3(64), 0, h->stream, ra);
+            }
         });
     } else {
         NB_DISPATCH(h->NB, {
@@ -996,6 +1011,7 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
         });
     }
     KCHECK();
+    if (fused_solve) return rebuild_R ? launch_build_R(h) : INSIDER_OK;
     int rc = do_allreduce(h, h->eq, (int64_t)ct.L * (h->KP * h->KP + h->KP));
     if (rc) return rc;
     if (cont && masked) {
@@ -1013,8 +1029,9 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
         });
     }
     KCHECK();
-    // the next covariate's Gauss-Seidel residual sees this update (:353-355, :347-349)
-    return launch_build_R(h);
+    // the next covariate's Gauss-Seidel residual sees this update (:353-355, :347-349): the per-sample path reads it from R;
+    // the merged update works from the stacked factors and the gene tables, so there only the last covariate rebuilds R
+    return rebuild_R ? launch_build_R(h) : INSIDER_OK;
 }
 
 struct LossOut {
@@ -1655,6 +1672,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "col_factored") h->col_factored = (int)value;   // 1 = cost model picks list / look-up / pair-count form (default), 2 = look-up form, 3 = pair-count form, 0 = k_list_stats
     else if (s == "row_counts") h->row_counts = (int)value;   // 1 = the merged row update takes u from the dense pair counts when they exist (default), 0 = from the entry lists
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
+    else if (s == "row_fused") h->row_fused = (int)value;     // 1 (default) = k_level_merged (one launch per covariate), 0 = k_level_pack / k_level_reduce / k_level_solve
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
@@ -1727,7 +1745,8 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
         if (masked && !use_merged(h, masked)) if ((rc = launch_row_stats(h, true))) return rc;
         if (use_merged(h, masked)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
         for (int i = 0; i < h->c; ++i) {
-            if ((rc = row_update(h, i, -1, masked, lambda1))) return rc;                        // :339
+            const bool need_R = !use_merged(h, masked) || i + 1 == h->c;
+            if ((rc = row_update(h, i, -1, masked, lambda1, need_R))) return rc;                // :339
             if (use_merged(h, masked) && i + 1 < h->c)
                 if ((rc = launch_gene_v(h, h->lvl_off[i], h->lvl_off[i + 1]))) return rc;
         }
@@ -1945,9 +1964,10 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
     int rc;
     if ((rc = bufs.alloc(&db, (size_t)nprob * K)) || (rc = bufs.alloc(&ds, (size_t)nprob))) return rc;
     const int ms = max_sweeps < 1 ? 1 : max_sweeps;
+    const int rows = std::min<int64_t>(ms, INSIDER_PERM_PERIOD);   // one period of the order sequence (include/insider_perm.h)
     uint8_t *dord = nullptr;
-    if ((rc = bufs.alloc(&dord, (size_t)(ms + 1) * ORDER_ROW))) return rc;   // + one row: the CD kernel prefetches ahead
-    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)ms * 64, 256)), dim3(256), 0, 0, seed, iter, K, ms, order_mode, K * 8,
+    if ((rc = bufs.alloc(&dord, (size_t)(rows + 4) * ORDER_ROW))) return rc;   // + the look-ahead row
+    hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)(rows + 1) * 64, 256)), dim3(256), 0, 0, seed, iter, K, rows, order_mode, K * 8,
                        reg_kmax(K), dord);
     KCHECK();
     CdParams cd;

@@ -195,7 +195,8 @@ struct CdParams {
     double lambda, alpha, tol;
     double la, l2;          // lambda * alpha, lambda * (1 - alpha): formed on the host so that they arrive in SGPRs
     int max_sweeps;
-    const uint8_t *order;   // [max_sweeps][ORDER_ROW], see k_order_table
+    const uint8_t *order;   // [min(max_sweeps, INSIDER_PERM_PERIOD) + 1][ORDER_ROW], see k_order_table: sweep s reads row
+                            // s mod INSIDER_PERM_PERIOD (include/insider_perm.h); the extra row is a copy of row 0 (look-ahead)
     // multi-pass solves (register-resident kernel, cold outer iterations): a pass covers sweeps [start_sweep, sweep_limit);
     // genes still running at sweep_limit save their state (beta, h, 1/D or 0) and are re-packed, by predicted remaining
     // length, into the waves of the next pass, which continues them bit-identically.  sweep_limit == 0: run to the end.
@@ -291,7 +292,8 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
     double bfinal = beta, gfinal = 0.0;
     uint32_t ordv = lane < K ? P.order[lane] : 0u;
     while (__any(run)) {
-        const uint32_t ordn = (lane < K && sweep + 1 < P.max_sweeps) ? P.order[(size_t)(sweep + 1) * ORDER_ROW + lane] : 0u;
+        const uint32_t ordn = (lane < K && sweep + 1 < P.max_sweeps)
+                                  ? P.order[(size_t)((sweep + 1) & (int)(INSIDER_PERM_PERIOD - 1)) * ORDER_ROW + lane] : 0u;
         // this sweep's coordinate list: the table row without the coordinates screened out in every group (:83)
         uint64_t am = __ballot(active);
         if constexpr (W == 32) am = (am | (am >> 32)) & 0xffffffffull;
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     __shared__ uint32_t keys[4][64];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = t >> 6, l = t & 63, w = threadIdx.x >> 6;
-    const bool live = s < nsweeps;
+    const bool live = s <= nsweeps;             // row nsweeps: the look-ahead row, the order of sweep nsweeps mod PERIOD
     uint8_t *row = order + (size_t)(live ? s : 0) * ORDER_ROW;
     // every coordinate's key once (K hashes per sweep, not K^2), ranks by counting over the shared copy
     const uint32_t key = insider_perm_key(insider_perm_base(seed, iter, (uint32_t)s), (uint32_t)l);

@@ -297,4 +297,80 @@ __global__ void __launch_bounds__(256) k_level_pack(const double *__restrict__ Y
     if (k == 0) { out[2 * KP] = (double)lvl_count[l]; out[2 * KP + 1] = 0.0; }
 }
 
+// level_pack + level_reduce (+ level_solve) of the merged update in ONE launch, one block per level: the three kernels are
+// 10 - 15 us each at c3 for 6 KB of work per level — launch and drain latency on the serial chain of the row phase.  Waves
+// 0..3 form sum_{r in l} s_r from the level-pair sample counts (k_level_pack's sum, same order); wave 0 then builds the
+// level's normal equations exactly as k_level_reduce does (eq is still written: the gene-sharded path all-reduces it) and,
+// with do_solve, solves them as k_level_solve does — same arithmetic on the same values, bit-identical results.
+template <int NB>
+__global__ void __launch_bounds__(256) k_level_merged(const double *__restrict__ rec /*[L][STAT + 2 KP + 2]: weighted-SYRK level sums*/,
+                                                      const double *__restrict__ Y /*[L][KP]*/,
+                                                      const double *__restrict__ paircnt /*[L][SL]*/, int SL,
+                                                      const double *__restrict__ Astack, const int *__restrict__ lvl_count,
+                                                      const double *__restrict__ CCt, const double *__restrict__ SC /*rows of this covariate*/,
+                                                      int L, int K, double lambda, int do_solve, double *__restrict__ eq,
+                                                      double *__restrict__ Arows /*L x KP*/, int *__restrict__ fail)
+{
+    constexpr int KP = Geo<NB>::KP, NBLK = Geo<NB>::NBLK, STAT = Geo<NB>::STAT;
+    __shared__ double red[4][64];
+    __shared__ double s_H[KP * KP];
+    __shared__ double s_A[NB <= 2 ? KP * KP : 1];   // the in-kernel solve is the register route (K <= 31); larger K: k_level_solve
+    __shared__ double s_s[KP];
+    const int l = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (l >= L) return;
+    double ss = 0.0;
+    if (lane < K)
+        for (int q = g; q < SL; q += 4) ss = fma(paircnt[(size_t)l * SL + q], Astack[(size_t)q * KP + lane], ss);
+    red[g][lane] = ss;
+    __syncthreads();
+    if (g != 0) return;
+    const bool valid = lane < K;
+    const int sub = lane >> 4, c16 = lane & 15;
+    const double cnt = (double)lvl_count[l];
+    const double v = valid ? Y[(size_t)l * KP + lane] : 0.0;
+    const double ssum = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const double *src = rec + (size_t)l * (STAT + 2 * KP + 2);
+    d4 h[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[b][q] = src[b * 256 + (sub + 4 * q) * 16 + c16];
+    acc_to_lds<NB>(h, s_H, lane);
+    if (lane < KP) s_s[lane] = ssum;
+    wave_sync();
+    double *eql = eq + (size_t)l * (KP * KP + KP);
+    for (int i = lane; i < KP * KP; i += WAVE) {
+        const int x = i / KP, y = i % KP;
+        const double e = (x < K && y < K) ? cnt * CCt[i] - s_H[i] : 0.0;
+        eql[i] = e;
+        if constexpr (NB <= 2) s_A[i] = e;
+    }
+    double yv = 0.0;
+    if (lane < KP) {
+        if (valid) {
+            yv = SC[(size_t)l * KP + lane] + v;
+            for (int b = 0; b < K; ++b) yv -= CCt[b * KP + lane] * s_s[b];      // CC' symmetric: coalesced
+        }
+        eql[KP * KP + lane] = yv;
+    }
+    if constexpr (NB <= 2) {
+        if (!do_solve || lvl_count[l] == 0) return;   // level without samples: the reference never visits it (:147)
+        wave_sync();
+        double b = lane < KP ? yv : 0.0;
+        double row[KP];
+#pragma unroll
+        for (int c = 0; c < KP; ++c) row[c] = lane < KP ? s_A[c * KP + lane] : 0.0;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) row[c] += (c == lane && lane < K) ? lambda : 0.0;      // :174,187
+        if (!gj_solve_regs<KP>(row, K, b, lane)) {                                          // :175,190; else the general route
+            wave_sync();
+            if (lane < K) s_A[lane * KP + lane] += lambda;
+            b = lane < KP ? yv : 0.0;
+            wave_sync();
+            if (!lu_solve_lds(s_A, KP, K, b, lane)) { if (lane == 0) *fail = 1; return; }
+        }
+        if (lane < K) Arows[(size_t)l * KP + lane] = b;
+    }
+}
+
 }  // namespace insider

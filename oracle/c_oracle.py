@@ -55,7 +55,7 @@ def set_cd_form(form=0):
     lib().oracle_set_cd_form(C.c_int(int(form)))
 
 
-def strong_cd_cov(wstart, lam, alpha, XtX, Xty, tol=1e-5, seed=0, it=0, order_mode=0, max_sweeps=10000):
+def strong_cd_cov(wstart, lam, alpha, XtX, Xty, tol=1e-5, seed=0, it=0, order_mode=0, max_sweeps=1 << 24):
     """Covariance-form variant of strong_cd (see set_cd_form). Returns (beta, sweeps)."""
     XtX = _f64(XtX)
     Xty = _f64(Xty)
@@ -83,7 +83,7 @@ def solve_sympd(A, b):
     return x
 
 
-def strong_cd(X, y, wstart, lam, alpha, XtX, Xty, tol=1e-5, seed=0, unit=0, it=0, order_mode=0, max_sweeps=10000):
+def strong_cd(X, y, wstart, lam, alpha, XtX, Xty, tol=1e-5, seed=0, unit=0, it=0, order_mode=0, max_sweeps=1 << 24):
     """strong_coordinate_descent (reference src/coordinate_descent.cpp:56-127). Returns (beta, sweeps)."""
     X = _f64(X)
     y = _f64(y)
@@ -149,7 +149,7 @@ def optimize_row(residual, M, A, Cmat, levels, gram, lam, tuning=1, n_threads=8)
     return A
 
 
-def optimize_col(X, M, R, Cmat, lam, alpha, tuning=1, tol=1e-5, seed=0, it=0, order_mode=0, max_sweeps=10000,
+def optimize_col(X, M, R, Cmat, lam, alpha, tuning=1, tol=1e-5, seed=0, it=0, order_mode=0, max_sweeps=1 << 24,
                  n_threads=8, gene_offset=0):
     X = _f64(X)
     M = np.asfortranarray(M, dtype=np.uint8)
@@ -168,7 +168,7 @@ def optimize_col(X, M, R, Cmat, lam, alpha, tuning=1, tol=1e-5, seed=0, it=0, or
 
 
 def optimize(X, levels, n_levels, A_list, Cmat, M_train, M_test, lam1, lam2, alpha, tuning=1, global_tol=1e-10,
-             sub_tol=1e-5, max_iter=10000, seed=0, order_mode=0, max_sweeps=10000, row_threads=10, col_threads=30,
+             sub_tol=1e-5, max_iter=10000, seed=0, order_mode=0, max_sweeps=1 << 24, row_threads=10, col_threads=30,
              traj_cap=4096, ctns=None):
     """The reference's optimize() (src/optimize.cpp:255-422), categorical covariates only.
 

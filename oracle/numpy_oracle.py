@@ -23,7 +23,11 @@ def h32(x):
     return x
 
 
+PERM_PERIOD = 16384      # include/insider_perm.h: the order sequence of a solve repeats after this many sweeps
+
+
 def perm_base(seed, it, sweep):
+    sweep &= PERM_PERIOD - 1
     b = h32((seed & M32) ^ 0x9E3779B9)
     b = h32(b ^ ((seed >> 32) & M32) ^ ((0x85EBCA6B * it) & M32))
     b = h32((b + 0xC2B2AE35 * sweep) & M32)

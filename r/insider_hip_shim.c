@@ -334,7 +334,7 @@ SEXP insider_hip_strong_cd_R(SEXP X, SEXP y, SEXP wstart, SEXP lambda, SEXP alph
     const int rc = insider_hip_strong_cd_xy(Rf_isNull(X) ? NULL : REAL(X), Rf_isNull(y) ? NULL : REAL(y), m, K, REAL(wstart),
                                             Rf_asReal(lambda), Rf_asReal(alpha), Rf_isNull(XtX) ? NULL : REAL(XtX),
                                             Rf_isNull(Xty) ? NULL : REAL(Xty), Rf_asReal(tol), (uint64_t)Rf_asReal(seed), 0u,
-                                            0 /* hashed random order */, 10000, Rf_asInteger(device), REAL(beta), NULL);
+                                            0 /* hashed random order */, 1 << 24 /* no effective sweep cap, like the reference */, Rf_asInteger(device), REAL(beta), NULL);
     UNPROTECT(1);
     if (rc == INSIDER_ERR_UNSUPPORTED || rc == INSIDER_ERR_NO_DEVICE) return R_NilValue;
     if (rc != INSIDER_OK) Rf_error("insider_hip (status %d): %s", rc, insider_hip_last_error());

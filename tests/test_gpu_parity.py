@@ -310,7 +310,7 @@ def test_optimize_options(oracle, opts):
     got = ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, max_iter=12, seed=31)
     ds.close()
     ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, max_iter=12,
-                          seed=31, order_mode=opts.get("order_mode", 0), max_sweeps=opts.get("max_sweeps", 10000))
+                          seed=31, order_mode=opts.get("order_mode", 0), max_sweeps=opts.get("max_sweeps", 1 << 24))
     np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
     assert relerr(got["column_factor"], ref["column_factor"]) < 1e-7
 
@@ -376,6 +376,25 @@ def test_split_column_step_is_bit_identical(oracle, K, frac):
                           max_iter=12, seed=9)
     assert relerr(two["column_factor"], ref["column_factor"]) < 1e-6
     np.testing.assert_allclose(two["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("K,levels", [(9, (7, 4)), (30, (12, 5, 3)), (40, (6, 5))])
+def test_fused_level_kernel_is_bit_identical(K, levels):
+    """The merged row update forms a level's record tail, its normal equations and (single rank, K <= 31) its ridge solve in
+    one launch (k_level_merged, option row_fused, default on) instead of three (k_level_pack / k_level_reduce /
+    k_level_solve): same arithmetic on the same values, so every result is bit-identical."""
+    w = workloads.small(K=K, n=140, p=260, level_counts=levels, f=0.2, seed=70 + K)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.set_option("row_merged", 2)
+    runs = []
+    for fused in (0, 1):
+        ds.set_option("row_fused", fused)
+        runs.append(ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=6, seed=5))
+    ds.close()
+    assert np.array_equal(runs[0]["column_factor"], runs[1]["column_factor"])
+    assert np.array_equal(runs[0]["traj"], runs[1]["traj"], equal_nan=True)
+    for i in range(len(w.A0)):
+        assert np.array_equal(runs[0]["row_matrices"][f"factor{i}"], runs[1]["row_matrices"][f"factor{i}"])
 
 
 def test_sweep_counts_match_oracle(oracle):
