@@ -16,9 +16,10 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds)."""
-    src = os.path.join(_HERE, "insider_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    deps = [os.path.join(_HERE, "insider_oracle.c"), os.path.join(_HERE, "Makefile"),
+            os.path.join(os.path.dirname(_HERE), "include", "insider_perm.h")]   # the sweep-order spec is shared with the HIP side
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"], stdout=subprocess.DEVNULL)
     return _SO
 
 
@@ -53,6 +54,16 @@ def set_cd_form(form=0):
     """0 = residual-form CD (the reference's formulation; the parity oracle), 1 = covariance-form sweeps (LABELLED
     CPU-optimised variant for bench.py's cpu_baseline, never used as the checker)."""
     lib().oracle_set_cd_form(C.c_int(int(form)))
+
+
+def sweep_order(K, seed, it, sweep, order_mode=0):
+    """Coordinate order of sweep `sweep` (include/insider_perm.h as the compiled oracle applies it)."""
+    out = np.zeros(K, dtype=np.int32)
+    rc = lib().oracle_sweep_order(C.c_int(K), C.c_uint64(seed), C.c_uint32(it), C.c_uint32(sweep), C.c_int(order_mode),
+                                  _p(out, C.c_int32))
+    if rc:
+        raise RuntimeError("oracle_sweep_order failed")
+    return out.tolist()
 
 
 def strong_cd_cov(wstart, lam, alpha, XtX, Xty, tol=1e-5, seed=0, it=0, order_mode=0, max_sweeps=1 << 24):

@@ -185,6 +185,16 @@ static void sweep_order(const int *inc, int ninc, uint64_t seed, uint32_t iter, 
     }
 }
 
+/* The order of sweep `sweep` over all K coordinates (tests: the shared spec of include/insider_perm.h). */
+int oracle_sweep_order(int K, uint64_t seed, uint32_t iter, uint32_t sweep, int mode, int *ord)
+{
+    int inc[64];
+    if (K < 1 || K > 64) return 1;
+    for (int k = 0; k < K; k++) inc[k] = k;
+    sweep_order(inc, K, seed, iter, sweep, mode, ord);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* strong_coordinate_descent — src/coordinate_descent.cpp:56-127             */
 /* ------------------------------------------------------------------------- */

@@ -4,6 +4,8 @@ The reference has no golden vectors (parity unpinned), so the orac
 a hand-computed K=1 case, KKT certificates, closed-form ridge, scikit-learn's ElasticNet as an independent
 solver, and an independent numpy restatement.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -90,6 +92,22 @@ def test_order_is_seeded_and_key_unique():
     o1 = NO.sweep_order(range(30), 5, 1, 2, 3, 0)
     o2 = NO.sweep_order(range(30), 5, 1, 2, 4, 0)
     assert sorted(o1) == list(range(30)) and o1 != o2 and o1 != list(range(30))
+
+
+def test_order_sequence_is_periodic(oracle):
+    """include/insider_perm.h: the order sequence of a solve repeats after INSIDER_PERM_PERIOD = 16384 sweeps (what lets the
+    HIP side keep a sweep-order table of fixed size and run without a sweep cap).  The numpy restatement and the compiled
+    oracle must both follow it: a solve stopped at 16384 + 7 sweeps equals, from sweep 16384 on, one restarted there."""
+    P = NO.PERM_PERIOD
+    assert P == 16384
+    assert NO.sweep_order(range(30), 5, 1, 2, 3, 0) == NO.sweep_order(range(30), 5, 1, 2, 3 + P, 0)
+    assert NO.sweep_order(range(30), 5, 1, 2, P - 1, 0) != NO.sweep_order(range(30), 5, 1, 2, 2 * P, 0)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "insider_perm.h")).read()
+    assert "#define INSIDER_PERM_PERIOD 16384u" in hdr
+    # the compiled oracle applies the same sequence as the numpy restatement, before and after the wrap
+    for sweep in (0, 1, 4097, P - 1, P, P + 1, 3 * P + 4097):
+        assert oracle.sweep_order(30, 5, 2, sweep) == NO.sweep_order(range(30), 5, 1, 2, sweep, 0), sweep
+    assert oracle.sweep_order(30, 5, 2, 4097) == oracle.sweep_order(30, 5, 2, 3 * P + 4097)
 
 
 def test_perm_uniformity_rough():

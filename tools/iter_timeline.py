@@ -1,19 +1,30 @@
-"""Print the kernel timeline of one steady-state outer iteration from a rocprofv3 kernel trace (per queue)."""
+"""Print the kernel timeline of one steady-state outer iteration from a rocprofv3 kernel trace (per queue).
+An outer iteration starts with the row phase's first kernel (k_mm_rows<4, true>: V = C A') after a column solve and ends
+with the last sweep-kernel launch of its column step.    python tools/iter_timeline.py DIR [iterations back from the end]"""
 import csv, glob, sys
 d = sys.argv[1]; back = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void insider::", "").replace("insider::", "")[:44], r["Queue_Id"]) for r in rows)
-cd = [i for i, e in enumerate(ev) if e[2].startswith("k_cd_cols_reg")]
-a, b = cd[-back], cd[-back + 1]
-t0 = ev[a][1]
-ints = sorted((e[0], e[1]) for e in ev[a + 1:b + 1])
+starts, seen_cd = [], True
+for i, e in enumerate(ev):
+    if e[2].startswith("k_cd_cols_reg"):
+        seen_cd = True
+    elif e[2].startswith("k_mm_rows<4, true>") and seen_cd:
+        starts.append(i)
+        seen_cd = False
+a, b = starts[-back - 1], starts[-back]
+it = ev[a:b]
+t0 = it[0][0]
+end = max(e[1] for e in it if e[2].startswith("k_cd_cols_reg"))
+ints = sorted((e[0], e[1]) for e in it)
 cs, ce = ints[0]; tot = 0
 for s, e in ints[1:]:
     if s > ce: tot += ce - cs; cs, ce = s, e
     else: ce = max(ce, e)
 tot += ce - cs
-print("iteration span us %.1f  union busy us %.1f  kernels %d" % ((ev[b][1] - ev[a][1]) / 1e3, tot / 1e3, b - a))
-qs = sorted(set(e[3] for e in ev[a + 1:b + 1]))
-for e in ev[a + 1:b + 1]:
+print("iteration span us %.1f (first row-phase kernel to the end of the column solve)  next iteration starts at %.1f  union busy us %.1f  kernels %d"
+      % ((end - t0) / 1e3, (ev[b][0] - t0) / 1e3, tot / 1e3, len(it)))
+qs = sorted(set(e[3] for e in it))
+for e in it:
     print("%9.1f %9.1f %8.1f q%d %s" % ((e[0] - t0) / 1e3, (e[1] - t0) / 1e3, (e[1] - e[0]) / 1e3, qs.index(e[3]), e[2]))

@@ -8,10 +8,18 @@ import __graft_entry__ as ge
 ge.build()
 from insider_amd import api, workloads
 n, p = workloads.CONFIGS["c4"][0], workloads.CONFIGS["c4"][1]
-for N in [int(v) for v in sys.argv[1:]] or [8, 4, 2]:
+args = sys.argv[1:]
+split = None
+if "--split" in args:      # option cd_split of the library (0 never, 2 always; default: what a sharded handle of this size takes)
+    i = args.index("--split")
+    split = int(args[i + 1])
+    del args[i:i + 2]
+for N in [int(v) for v in args] or [8, 4, 2]:
     w = workloads.make("c4", gene_range=(0, p // N))
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
     ds.set_option("profile", 1)
+    if split is not None:
+        ds.set_option("cd_split", split)
     def run(iters, seed, init_seed, lam):
         A0, C0 = workloads.init_factors(w.n_levels, w.K, p, init_seed)
         C0 = np.asfortranarray(C0[:, : p // N])
@@ -21,6 +29,6 @@ for N in [int(v) for v in sys.argv[1:]] or [8, 4, 2]:
     run(1, 2, 8, 3.0)
     dt = run(11, 1, 7, w.lam)
     pr = ds.profile()
-    print(f"c4 / {N}: {p // N} genes: {dt / 11 * 1e3:.3f} ms per outer iteration ({11 / dt:.1f} it/s); ideal from the whole problem: {16.5 / N:.3f} ms; "
+    print(f"cd_split={split} c4 / {N}: {p // N} genes: {dt / 11 * 1e3:.3f} ms per outer iteration ({11 / dt:.1f} it/s); ideal from the whole problem: {16.5 / N:.3f} ms; "
           f"cd {pr['cd_ms'] / 11:.3f} ms, statistics {pr['col_stats_ms'] / 11:.3f} ms per iteration", flush=True)
     ds.close()

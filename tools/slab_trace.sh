@@ -1,6 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/slab8
+OUT=$R/gpurun_out/slab8_s${1:-2}
+rm -rf $OUT/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/slab_run.py <<PY
@@ -10,6 +11,7 @@ from insider_amd import api, workloads
 p = workloads.CONFIGS["c4"][1]
 w = workloads.make("c4", gene_range=(0, p // 8))
 ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+ds.set_option("cd_split", ${1:-2})
 A0, C0 = workloads.init_factors(w.n_levels, w.K, p, 7)
 ds.optimize(A0, np.asfortranarray(C0[:, : p // 8]), w.K, w.lam, w.lam, w.alpha, max_iter=30, global_tol=-1, seed=1)
 ds.close()
