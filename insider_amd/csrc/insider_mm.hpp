@@ -68,41 +68,24 @@ __global__ void __launch_bounds__(64) k_mm_reduce(const double *__restrict__ X, 
     d4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-    // four MFMA steps per trip of 16 rows; the loads of trip t + 1 are issued before the MFMAs of trip t (two operand sets): a
-    // wave has only per / 16 = 8 trips, so without the look-ahead every trip waits out a full memory latency
-    auto load = [&](int m0, double (&a)[4], double (&b)[4][NT]) {
+    for (int m0 = m_begin; m0 < m_end; m0 += 16) {   // four MFMA steps per trip, loads first
+        double a[4], b[4][NT];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int m = m0 + 4 * s + g;
             const bool min_ = m < m_end;
             const size_t mr = (size_t)(min_ ? m : m_end - 1);
-            const double av = X[mr * ldx + (lin ? l : 0)];
-            a[s] = (min_ && lin) ? av : 0.0;
+            a[s] = (min_ && lin) ? X[mr * ldx + l] : 0.0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int n = 16 * t + c16;
-                const double bv = Y[mr * ldy + (n < N ? n : 0)];
-                b[s][t] = (min_ && n < N) ? bv : 0.0;
+                b[s][t] = (min_ && n < N) ? Y[mr * ldy + n] : 0.0;
             }
         }
-    };
-    auto mfma = [&](const double (&a)[4], const double (&b)[4][NT]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][t], acc[t], 0, 0, 0);
-    };
-    if (m_begin < m_end) {
-        double a0[4], b0[4][NT], a1[4], b1[4][NT];
-        load(m_begin, a0, b0);
-        for (int m0 = m_begin; m0 < m_end; m0 += 32) {
-            load(m0 + 16 < m_end ? m0 + 16 : m_end - 1, a1, b1);      // past the end: one row re-read, masked to zero
-            mfma(a0, b0);
-            if (m0 + 16 < m_end) {
-                load(m0 + 32 < m_end ? m0 + 32 : m_end - 1, a0, b0);
-                mfma(a1, b1);
-            }
-        }
     }
     double *out = part + (size_t)blockIdx.x * L * ldo;
 #pragma unroll
