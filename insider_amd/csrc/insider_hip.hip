@@ -176,7 +176,7 @@ struct insider_hip_handle {
     int *sched_long = nullptr;        // device: {n_long, last long bucket} of the current gene_perm (k_sched_scatter)
     bool sched_long_valid = false;
     int n_simd = 1024;                // SIMDs of the device (4 per CU)
-    int cd_split = 1;                 // option "cd_split"
+    int cd_split = 0;                 // option "cd_split"
     double cd_long_frac = 0.03;       // option "cd_long_frac"
     hipStream_t lng = nullptr;
     hipEvent_t ev_long_go = nullptr, ev_long_done = nullptr;
@@ -545,14 +545,14 @@ bool use_split(const insider_hip_handle *h, int masked, double alpha, int outer_
           outer_iter >= std::max(h->cd_cold_iters, (int)insider_hip_handle::EARLY) && h->have_perm && h->sched_long_valid &&
           long_cap(h) >= 4))
         return false;
-    if (h->cd_split >= 2) return true;   // forced
-    // Worth it when the solve is bound by its longest gene AND the statistics are a sizeable head start.  Measured (round 3):
-    // a 25000-gene slab of c4 (one rank of the 8-GPU configuration) 1.36 -> 1.18 ms per steady iteration; c3's 50000 genes on
-    // one GPU are throughput-bound and lose 2 % (the long genes' sweeps next to the others' MFMA-bound statistics cost more
-    // than the head start); c2 (20000 genes, statistics 0.1 of 1.3 ms) loses 3 %.  Default: gene-sharded handles whose slab
-    // fills the GPU's wave slots at most three times over.
-    const int64_t slots = (int64_t)h->n_simd * reg_waves(reg_kmax(h->K)) * 4;
-    return h->world > 1 && h->p <= 3 * slots;
+    // Not on by default.  Measured on a 25000-gene slab of c4 (one rank of the 8-GPU configuration; tools/slab_trace.sh,
+    // tools/tail_probe.py): the launch order predicts the tail well (the 50 longest genes of a solve are all among its first
+    // 3 %, correlation of consecutive sweep counts 0.95), but the tail is BROAD, not a few outliers (median 171, p99 415, max
+    // 612 sweeps; the longest gene outside the first 10 % still needs 425), and a long gene advances at 1 / 3 of the SIMD's
+    // rate while the SIMD is full.  So the launch that holds everyone else is barely shorter than the whole solve (0.69 -
+    // 0.72 ms against 0.73), and the long genes' sweeps next to the others' MFMA-bound statistics slow those down: 1.26 ms
+    // per steady iteration unsplit, 1.30 / 1.33 / 1.40 ms with 3 / 10 / 25 % of the genes split off.
+    return h->cd_split >= 2;   // forced
 }
 
 // masked Gram/XtY complement statistics of every gene (column side of src/optimize.cpp:216-222)
@@ -1676,7 +1676,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
-    else if (s == "cd_split") h->cd_split = (int)value;           // steady-state column steps run split (long genes first, on their own stream): 1 (default) = gene-sharded handles whose slab fills the wave slots at most 3 times, 2 = always, 0 = never
+    else if (s == "cd_split") h->cd_split = (int)value;           // 2 = steady-state column steps run split (long genes first, on their own stream); 0 (default) = never (measured: no gain, see use_split)
     else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);

@@ -61,7 +61,7 @@ def main():
     # and save / restore 3 KP doubles per gene): the single-launch figure is the LAST launch of the run (outer iteration 3 of
     # the 4-step command), the largest launch and the mean over all launches are kept beside it
     fs, ws = series(fdir, "FETCH_SIZE"), series(wdir, "WRITE_SIZE")
-    cdk = [k for k in fs if k.startswith("k_cd_cols")]
+    cdk = [k for k in fs if k.startswith("k_cd_cols") and not k.endswith("false>")]   # the solve launches (not the checkpoint evaluation)
     cd_launch = []
     for k in cdk:
         cd_launch += [1024.0 * (2.0 * f + w) for f, w in zip(fs[k], ws.get(k, [0.0] * len(fs[k])))]

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/slab8_s${1:-2}
+OUT=$R/gpurun_out/slab8_s${1:-2}_f${2:-0.03}
 rm -rf $OUT/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -12,6 +12,7 @@ p = workloads.CONFIGS["c4"][1]
 w = workloads.make("c4", gene_range=(0, p // 8))
 ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
 ds.set_option("cd_split", ${1:-2})
+ds.set_option("cd_long_frac", ${2:-0.03})
 A0, C0 = workloads.init_factors(w.n_levels, w.K, p, 7)
 ds.optimize(A0, np.asfortranarray(C0[:, : p // 8]), w.K, w.lam, w.lam, w.alpha, max_iter=30, global_tol=-1, seed=1)
 ds.close()
