@@ -116,10 +116,10 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * entry, 2 = per-(covariate, level) terms with one table look-up per entry, 3 = per-(covariate, level) terms from the
  * gene's dense level-pair counts [falls back to 2 when a count exceeds one byte]; same results), "row_counts" (1, default = the merged row update takes its per-gene level sums from the dense
  * level-pair counts when they exist, 0 = from the entry lists; same results), "force_allreduce" (1 = call the all-reduce callback even
- * when world == 1: plumbing rehearsal), "cd_split" / "cd_long_frac" (steady-state column steps run split: the genes predicted longest — whole buckets of the
+ * when world == 1: plumbing rehearsal), "cd_split" / "cd_long_frac" (2 = steady-state column steps run split: the genes predicted longest — whole buckets of the
  * launch order, at most cd_long_frac [0.03] of the genes — get their statistics and their solve on a stream of their own, ahead
- * of the others' statistics; 1 [default] = on gene-sharded handles whose slab fills the GPU's wave slots at most three times, 2 =
- * always, 0 = never; bit-identical results), "row_fused" (1, default = the merged row update forms a level's equations and
+ * of the others' statistics; bit-identical results; 0 [default] = off: measured, it does not shorten the step),
+ * "row_fused" (1, default = the merged row update forms a level's equations and
  * solve in one launch), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
  * cd_cold_iters outer iterations of a call [default 3]: the register-resident sweep kernel stops at sweep cd_pass1 [64; 0 = one
  * pass], cd_pass1 x ratio [4], ..., re-packing the genes still running by their estimated remaining length between passes;

@@ -24,36 +24,42 @@ constexpr int REG_ORDER_OFF = 128;   // byte offset of the block-offset dwords i
 static_assert(ORDER_ROW == 0x140, "the sweep prologue prefetches the next row at +0x140");
 constexpr int REG_BLOCK = 96;        // bytes between the code blocks of consecutive coordinates (see REG_BLOCK_HEAD)
 
+// The sweep state in the SCALED form the step works on (round 3): with la = lambda alpha > 0
+//   y   = h / (2 la) + 1/2      h = Xty - offdiag(XtX) beta, the gradient part of src/coordinate_descent.cpp:94
+//   tau = 2 la / (XtX_kk + l2)  (0 for a screened-out coordinate or a parked gene)
+// and the Gram registers hold G / (2 la).  Then  soft(h, la) = h - clamp(h, -la, la) = 2 la (y - clamp01(y)), and the
+// hardware's output clamp to [0, 1] does the soft threshold in ONE instruction where min + max took two:
+//   c = clamp01(y);  e = y - c;  dn = beta - e tau  (minus the increment);  beta -= dn;  y_u += bcast(dn) Ghat_u[k]
+// — 4 + 2 vector instructions per step instead of 5 + 2, and a dependent chain of 3 before the DPP fmacs instead of 4.
+// Exact zeros survive: |h| <= la  <=>  0 <= y <= 1  =>  c = y, e = 0, dn = beta, beta - dn = 0 exactly.  The offset costs
+// no accuracy that matters: y is rounded at 1.1e-16 absolute, i.e. h at 2.2e-16 la.
 template <int SLOTS>
 struct RegState {
-    double h[SLOTS], beta[SLOTS], inv[SLOTS];
+    double y[SLOTS], beta[SLOTS], tau[SLOTS];
 };
 
 // ---- the sweep as one asm block -----------------------------------------------------------------------------------
 // Block for coordinate KK (slot s = KK / 16, owner lane it = KK % 16), src/coordinate_descent.cpp:91-110 in covariance
-// form, on the owner lanes: x = soft(h_s, la); dn = beta_s - x inv_s (one fma: minus the increment); beta_s -= dn; on all lanes:
-// h_u += bcast_it(dn) * G_u[KK].  soft(h, la) = h - clamp(h, -la, la); x = 0 gives dn = beta_s and beta_s[it] = 0 exactly.  Screened-out coordinates and parked genes carry inv = beta = 0, i.e. a zero increment.
+// form on the scaled state (above); screened-out coordinates and parked genes carry tau = beta = 0, i.e. a zero increment.
 // The sweep's order arrives as a successor list of code-block offsets (k_order_table: dword 0 = first block, dword 1 + k
 // = the block visited after coordinate k, the exit block after the last), loaded into s[64:97] at the start of the sweep
 // (offsets: each block adds the table's base address, s98, itself); the table of blocks (REG_BLOCK bytes apart, placed with .org,
 // which also asserts that no block outgrows its slot) starts on a 4 KiB boundary and is shorter than 4 KiB, so it cannot
 // straddle a 4 GiB boundary and the high word of every block address is the same (vcc_hi, set once).  Block k forms its
 // successor's address from its own table register s[65 + k] in vcc_lo while the vector chain runs, and jumps: no
-// position counter, M0 untouched.  Critical chain per step: min, max, add, fma (dn), DPP fmac.  Hazards respected by
+// position counter, M0 untouched.  Critical chain per step: clamp, sub, fma (dn), DPP fmac.  Hazards respected by
 // construction: >= 2 instructions between the write of dn and its DPP read; exec is written by SALU only; nothing in a
 // block writes vcc_hi.
-// The five scalar-like instructions of a step (soft threshold, increment, beta update) do useful work on the owner lane of each
-// row only: they run under a four-lane exec mask (the DPP fmacs that follow need every lane).  Same instruction count as
-// narrowing the mask around the beta update alone, but the part sustains a higher clock: 200.5 -> 208.6 G coordinate updates/s
-// at c3 (round 3, tools/ab_variants.sh), bit-identical results.
+// The four scalar-like instructions of a step do useful work on the owner lane of each row only: they run under a four-lane
+// exec mask (the DPP fmacs that follow need every lane).  Same instruction count as narrowing the mask around the beta
+// update alone, but the part sustains a higher clock (round 3, tools/ab_variants.sh: +4 % sweep rate, bit-identical).
 #define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
     ".org Lc%= + 96*" #KK "\n"                                   \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
     "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
-    "v_min_f64 %[c], %[" HS "], %[la]\n"                         \
-    "v_max_f64 %[c], %[c], -%[la]\n"                             \
-    "v_add_f64 %[c], %[" HS "], -%[c]\n"                         \
-    "v_fma_f64 %[dn], -%[c], %[" IS "], %[" BS "]\n"             \
+    "v_max_f64 %[dn], %[" HS "], %[" HS "] clamp\n"              \
+    "v_add_f64 %[dn], %[" HS "], -%[dn]\n"                       \
+    "v_fma_f64 %[dn], -%[dn], %[" IS "], %[" BS "]\n"            \
     "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
     "s_mov_b64 exec, -1\n"
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
@@ -106,25 +112,25 @@ struct RegState {
 #define REG_HB_30(F) REG_HB_28(F) F(28, 12) F(29, 13)
 #define REG_HB_32(F) REG_HB_30(F) F(30, 14) F(31, 15)
 
-// tb: this sweep's block-offset dwords (order-table row + REG_ORDER_OFF); la in SGPRs
+// tb: this sweep's block-offset dwords (order-table row + REG_ORDER_OFF)
 #if defined(__HIP_DEVICE_COMPILE__)   // gfx950 assembly: hipcc's host pass must not parse it
 #define REG_DEFINE_SWEEP2(KMAX)                                                                                          \
-    __device__ __forceinline__ void reg_sweep(RegState<2> &S, const double (&G)[2][KMAX], double la, const uint32_t *tb) \
+    __device__ __forceinline__ void reg_sweep(RegState<2> &S, const double (&G)[2][KMAX], const uint32_t *tb)            \
     {                                                                                                                    \
-        double c, dn;                                                                                                    \
+        double dn;                                                                                                       \
         int sk, p1, p2;                                                                                                  \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
         asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                       \
-                     : [h0] "+v"(S.h[0]), [h1] "+v"(S.h[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), [c] "=&v"(c),   \
+                     : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]),                 \
                        [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2)                                   \
                      : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(      \
-                           S.inv[0]),                                                                                    \
-                       [i1] "v"(S.inv[1]), [la] "s"(la), [tb] "s"(tb), [lm] "s"(lm)                                      \
+                           S.tau[0]),                                                                                    \
+                       [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm)                                                    \
                      : REG_CLOBBERS);                                                                                    \
     }
 #else
 #define REG_DEFINE_SWEEP2(KMAX) \
-    __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][KMAX], double, const uint32_t *) {}
+    __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][KMAX], const uint32_t *) {}
 #endif
 REG_DEFINE_SWEEP2(18)
 REG_DEFINE_SWEEP2(20)
@@ -135,16 +141,16 @@ REG_DEFINE_SWEEP2(28)
 REG_DEFINE_SWEEP2(30)
 REG_DEFINE_SWEEP2(32)
 
-__device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][16], double la, const uint32_t *tb)
+__device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][16], const uint32_t *tb)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double c, dn;
+    double dn;
     int sk, p1, p2;
     const uint64_t lm = 0x0001000100010001ull;
     asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16)
-                 : [h0] "+v"(S.h[0]), [b0] "+v"(S.beta[0]), [c] "=&v"(c), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
+                 : [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
                    [p2] "=&s"(p2)
-                 : REG_LIST_LO(REG_GA)[i0] "v"(S.inv[0]), [la] "s"(la), [tb] "s"(tb), [lm] "s"(lm)
+                 : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), [tb] "s"(tb), [lm] "s"(lm)
                  : REG_CLOBBERS);
 #endif
 }
@@ -173,7 +179,7 @@ __device__ __forceinline__ void reg_gemv(double (&acc)[SLOTS], const double (&v)
 #undef REG_G
 }
 
-// LDS doubles per wave: per lane and slot D = XtX_kk + l2, the sweep-start beta and w = beta D - h, and the solution
+// LDS doubles per wave: per lane and slot D / (2 la) (D = XtX_kk + l2), the sweep-start beta and what = beta D / (2 la) - y, and the solution
 // (values that are not needed inside the sweep live here so that the registers hold only the Gram columns and the
 // sweep state)
 constexpr int REG_STASH = 6 * 2 * 64;   // D, beta0, w0, solution | two 64-entry windows of |loss change| sums (multi-pass:
@@ -187,12 +193,14 @@ constexpr int REG_STASH = 6 * 2 * 64;   // D, beta0, w0, solution | two 64-entry
 // Loss change of a sweep (:112-114) from per-coordinate start/end values: with g = h - beta XtX_kk (the gradient part
 // Xty - XtX beta) the exact change is sum_l [-1/2 db (g0 + g1) + 1/2 l2 (b1^2 - b0^2) + la (|b1| - |b0|)]
 // = sum_l [1/2 db (w0 + w1) + la (|b1| - |b0|)],  w = beta (XtX_kk + l2) - h;  the end values of one sweep are the
-// start values of the next.  Lanes without a coordinate carry h = beta = 0 and contribute nothing.
+// start values of the next.  In the solver's scaled units (RegState) w = 2 la (what + 1/2), what = beta D / (2 la) - y, so the
+// change is la sum_l [db (what0 + what1 + 1) + |b1| - |b0|].  Lanes without a coordinate carry y = 1/2, beta = 0 and
+// contribute nothing.
 // Multi-pass (P.sweep_limit / P.start_sweep): with `resume` the row continues a solve that an earlier pass stopped at sweep
 // P.start_sweep — hs / is hold its saved h and 1/D-or-0, beta its saved iterate, and nothing is re-derived (the loss
 // bookkeeping values beta0 = beta, w0 = beta D - h are the ones the single-pass solve would hold at that sweep), so the
 // iterates are bit-identical to an uninterrupted solve.  A row still running when the pass ends at P.sweep_limit returns
-// unfinished = true with its state in hs / is / beta and `key` = its estimated remaining sweeps (from the geometric decay
+// unfinished = true with its (scaled) state in hs / is / beta and `key` = its estimated remaining sweeps (from the geometric decay
 // of the loss change over the last two 8-sweep windows; > 0).
 // Start values WITHOUT the Gram matrix (so that the kernels can fetch it afterwards: the start values' inputs and the
 // 2 x KMAX matrix registers are then never live together): screening, beta, 1/D, h = q (the caller's matrix product
@@ -204,7 +212,7 @@ __device__ __forceinline__ RegState<SLOTS> cd_reg_begin(int K, const double (&q)
                                                         const double (&is)[SLOTS])
 {
     const int i = lane & 15;
-    const double l2 = P.l2;
+    const double l2 = P.l2, two_la = P.two_la, gs = P.inv_two_la;   // the scaled state: RegState
     double *s_d = stash + lane, *s_out = s_d + 384, *s_ri = s_d + 640;   // [slot * 64]
     RegState<SLOTS> S;
     if (!resume) {
@@ -219,9 +227,9 @@ __device__ __forceinline__ RegState<SLOTS> cd_reg_begin(int K, const double (&q)
             const bool active = valid && !(fabs(q[u]) < thr);
             const double D = (valid ? Gll[u] : 1.0) + l2, rD = cd_rcp(D);
             S.beta[u] = active ? beta[u] : 0.0;                                           // :78
-            S.inv[u] = active ? rD : 0.0;
-            S.h[u] = valid ? q[u] : 0.0;
-            s_d[64 * u] = D;
+            S.tau[u] = active ? two_la * rD : 0.0;
+            S.y[u] = valid ? fma(q[u], gs, 0.5) : 0.5;      // h = q here; cd_reg subtracts offdiag(XtX) beta with the scaled matrix
+            s_d[64 * u] = D * gs;
             s_ri[64 * u] = rD;
             s_out[64 * u] = S.beta[u];
         }
@@ -230,10 +238,10 @@ __device__ __forceinline__ RegState<SLOTS> cd_reg_begin(int K, const double (&q)
         for (int u = 0; u < SLOTS; ++u) {   // the state a limited pass saved: no screening, no re-derivation
             const bool valid = gene_ok && 16 * u + i < K;
             S.beta[u] = valid ? beta[u] : 0.0;
-            S.inv[u] = valid ? is[u] : 0.0;
-            S.h[u] = valid ? hs[u] : 0.0;
+            S.tau[u] = valid ? is[u] : 0.0;
+            S.y[u] = valid ? hs[u] : 0.5;
             const double D = (valid ? Gll[u] : 1.0) + l2;
-            s_d[64 * u] = D;
+            s_d[64 * u] = D * gs;
             s_ri[64 * u] = cd_rcp(D);
             s_out[64 * u] = S.beta[u];
         }
@@ -250,11 +258,11 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
     const int i = lane & 15;
     // the scalars the sweep loop needs, copied out of the kernel-argument tuple: the sweep's assembly clobbers s63-s99,
     // and the compiler otherwise keeps the s_load_dwordx8 result there and restores it (8 v_readlane) twice per sweep
-    double la = P.la, tol = P.tol;
+    double la = P.la, tol = P.tol, two_la = P.two_la;   // h = 2 la y - la
     int max_sweeps = P.max_sweeps;
     const uint8_t *order = P.order;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(la), "+s"(tol), "+s"(max_sweeps), "+s"(order));
+    asm volatile("" : "+s"(la), "+s"(tol), "+s"(two_la), "+s"(max_sweeps), "+s"(order));
 #endif
     double *s_d = stash + lane, *s_b = s_d + 128, *s_w = s_d + 256, *s_out = s_d + 384;   // [slot * 64]
     double *s_acc = s_d + 512;                                                           // [window * 64]
@@ -264,11 +272,12 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
     unfinished = false;
     capped = false;
     key = 0;
-    if (!resume) reg_gemv<SLOTS, KMAX>(S.h, S.beta, G, K);                                // :79 h = q - offdiag(XtX) beta
+    if (!resume) reg_gemv<SLOTS, KMAX>(S.y, S.beta, G, K);                                // :79 h = q - offdiag(XtX) beta (G scaled)
+    // loss bookkeeping in the scaled units too: what = w / (2 la) - 1/2 = beta D / (2 la) - y, w = beta D - h (below)
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         s_b[64 * u] = S.beta[u];
-        s_w[64 * u] = fma(S.beta[u], s_d[64 * u], -S.h[u]);
+        s_w[64 * u] = fma(S.beta[u], s_d[64 * u], -S.y[u]);
     }
 
     // Loop control lives in scalar registers: `runm` = lane mask of the genes still running (a wave-uniform integer,
@@ -290,7 +299,7 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
     const uint32_t *tb = tb0 + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * (ORDER_ROW / 4);
     while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
-        reg_sweep(S, G, la, tb);
+        reg_sweep(S, G, tb);
         ++sweep;
         tb = (sweep & (int)(INSIDER_PERM_PERIOD - 1)) ? tb + ORDER_ROW / 4 : tb0;
         // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
@@ -298,13 +307,13 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
             const double beta0 = s_b[64 * u];
-            const double w1 = fma(S.beta[u], s_d[64 * u], -S.h[u]);
-            acc = fma(S.beta[u] - beta0, w1 + s_w[64 * u], acc);
+            const double w1 = fma(S.beta[u], s_d[64 * u], -S.y[u]);
+            acc = fma(S.beta[u] - beta0, (w1 + s_w[64 * u]) + 1.0, acc);
             acc1 += fabs(S.beta[u]) - fabs(beta0);
             s_b[64 * u] = S.beta[u];
             s_w[64 * u] = w1;
         }
-        const double dloss = row16_sum(fma(la, acc1, 0.5 * acc));
+        const double dloss = row16_sum(la * (acc1 + acc));
         if (sweep > win) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);                   // wave-uniform, limited passes only
         const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
         if (cand != 0) {                                                                    // wave-uniform, rarely taken
@@ -319,8 +328,8 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
             if (mine) {
 #pragma unroll
                 for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
-                    const bool viol = gene_ok && 16 * u + i < K && S.inv[u] == 0.0 && fabs(S.h[u]) > la;
-                    if (viol) S.inv[u] = s_ri[64 * u];                                      // :123
+                    const bool viol = gene_ok && 16 * u + i < K && S.tau[u] == 0.0 && fabs(fma(S.y[u], two_la, -la)) > la;
+                    if (viol) S.tau[u] = two_la * s_ri[64 * u];                             // :123
                     anyv = anyv || viol;
                 }
             }
@@ -331,7 +340,7 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
                 for (int u = 0; u < SLOTS; ++u) {
                     s_out[64 * u] = S.beta[u];
                     S.beta[u] = 0.0;
-                    S.inv[u] = 0.0;
+                    S.tau[u] = 0.0;
                 }
             }
             runm &= ~__ballot(finish);
@@ -344,7 +353,7 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
         if (sweep < max_sweeps) {   // to be continued by the next pass
             unfinished = true;
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) { hs[u] = S.h[u]; is[u] = S.inv[u]; }
+            for (int u = 0; u < SLOTS; ++u) { hs[u] = S.y[u]; is[u] = S.tau[u]; }   // the scaled state, as it stands
             // |loss change| decays geometrically: rho^W = b / a over the last two W-sweep windows; sweeps until it reaches tol.
             // Single precision: the estimate only picks a bucket of the next pass's launch order (8 per octave), never a result,
             // and a double-precision log would cost ~20 registers next to the Gram matrix
@@ -428,6 +437,7 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
     const int lane = threadIdx.x;
     const int K = a.K, KP = a.KP;
     const bool resume = a.resume != 0;
+    const double gs = a.cd.inv_two_la;
     __shared__ double stash[REG_STASH];
     double G[SLOTS][KMAX], beta[SLOTS], hs[SLOTS], is[SLOTS];
     bool unfinished = false, capped = false;
@@ -472,7 +482,7 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
                 const int si = bk >= u ? (bk * (bk + 1) / 2 + u) * 256 + (k & 15) * 16 + w.i
                                        : (u * (u + 1) / 2 + bk) * 256 + w.i * 16 + (k & 15);
                 const double v = w.st ? w.st[si] : a.RtR[k * KP + c];
-                G[u][k] = (ok && k < K && k != c) ? v : 0.0;
+                G[u][k] = (ok && k < K && k != c) ? (SOLVE ? v * gs : v) : 0.0;   // the sweeps work on XtX / (2 la): RegState
             }
         }
         if constexpr (SOLVE)                                                              // :228,246
@@ -551,8 +561,10 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
 }
 
 // stand-alone batch form (insider_hip_strong_cd) on dense (XtX, Xty)
+// (two waves per SIMD from KMAX = 30 on: the dense problems' per-element addresses need registers the column-update kernel
+// does not, and the stand-alone solver is not on the fit's path; no instantiation spills)
 template <int SLOTS, int KMAX>
-__global__ void __launch_bounds__(64, reg_waves(KMAX))
+__global__ void __launch_bounds__(64, KMAX >= 30 ? 2 : reg_waves(KMAX))
 k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, const double *__restrict__ wstart, int K,
                int64_t nprob, CdParams cd, double *__restrict__ beta_out, int *__restrict__ sweeps_out)
 {
@@ -594,7 +606,7 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 const double v = Gb[(size_t)(k < K ? k : 0) * K + cc];
-                G[u][k] = (ok && k < K && k != c) ? v : 0.0;
+                G[u][k] = (ok && k < K && k != c) ? v * cd.inv_two_la : 0.0;   // the sweeps work on XtX / (2 la): RegState
             }
         }
         bool unfinished, capped;

@@ -548,9 +548,9 @@ bool use_split(const insider_hip_handle *h, int masked, double alpha, int outer_
     // Not on by default.  Measured on a 25000-gene slab of c4 (one rank of the 8-GPU configuration; tools/slab_trace.sh,
     // tools/tail_probe.py): the launch order predicts the tail well (the 50 longest genes of a solve are all among its first
     // 3 %, correlation of consecutive sweep counts 0.95), but the tail is BROAD, not a few outliers (median 171, p99 415, max
-    // 612 sweeps; the longest gene outside the first 10 % still needs 425), and a long gene advances at 1 / 3 of the SIMD's
-    // rate while the SIMD is full.  So the launch that holds everyone else is barely shorter than the whole solve (0.69 -
-    // 0.72 ms against 0.73), and the long genes' sweeps next to the others' MFMA-bound statistics slow those down: 1.26 ms
+    // 612 sweeps; the longest gene outside the first 10 % still needs 425).  So the launch that holds everyone else is barely
+    // shorter than the whole solve (0.69 - 0.72 ms against 0.73, which is what the longest gene takes alone), and the long
+    // genes' sweeps next to the others' MFMA-bound statistics slow those down: 1.26 ms
     // per steady iteration unsplit, 1.30 / 1.33 / 1.40 ms with 3 / 10 / 25 % of the genes split off.
     return h->cd_split >= 2;   // forced
 }
@@ -685,6 +685,8 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.cd.tol = tol;
         a.cd.la = lambda * alpha;
         a.cd.l2 = lambda * (1.0 - alpha);
+        a.cd.two_la = 2.0 * a.cd.la;
+        a.cd.inv_two_la = a.cd.la > 0.0 ? 0.5 / a.cd.la : 0.0;
         a.cd.max_sweeps = h->max_sweeps;
         a.cd.order = h->order;
         a.sse_train = h->sse_train;
@@ -706,7 +708,9 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.bucket_cnt = nullptr;
         a.cap_hits = solve ? h->failflag + 2 : nullptr;
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
-        if (h->cd_variant == 0 && h->K <= 32) {
+        // the register-resident kernel scales its state by 1 / (2 lambda alpha): lambda alpha = 0 (alpha < 0 or lambda = 0: no l1
+        // term at all) takes the group kernel below
+        if (h->cd_variant == 0 && h->K <= 32 && a.cd.la > 0.0) {
             // Cold outer iterations: thousands of sweeps per gene whose counts no history predicts, so a wave's four genes
             // finish far apart (measured at c3: 1.17x / 1.44x / 2.1x the ideal wave time in outer iterations 0 / 1 / 2).
             // The solve then runs in passes over geometrically growing sweep ranges: a limited pass stops at its sweep
@@ -1976,6 +1980,8 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
     cd.tol = tol;
     cd.la = lambda * alpha;
     cd.l2 = lambda * (1.0 - alpha);
+    cd.two_la = 2.0 * cd.la;
+    cd.inv_two_la = cd.la > 0.0 ? 0.5 / cd.la : 0.0;
     cd.max_sweeps = ms;
     cd.order = dord;
     hipEvent_t e0, e1;
@@ -1992,10 +1998,12 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
         hipLaunchKernelGGL((k_cd_batch_r16<1>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32 && lds_variant)
         hipLaunchKernelGGL((k_cd_batch_r16<2>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
-    else if (K <= 32) {
+    else if (K <= 32 && cd.la > 0.0) {   // (the register-resident solver's state is scaled by 1 / (2 lambda alpha))
         REG_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0, dG, dq, dw, K,
                                            nprob, cd, db, ds));
-    } else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
+    } else if (K <= 16) hipLaunchKernelGGL((k_cd_batch<16, 4>), dim3(cdiv(nprob, 16)), dim3(256), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
+    else if (K <= 32) hipLaunchKernelGGL((k_cd_batch<32, 2>), dim3(cdiv(nprob, 4)), dim3(128), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
+    else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     KCHECK();
     HIPCHECK(hipEventRecord(e1, 0));
     HIPCHECK(hipDeviceSynchronize());

@@ -194,6 +194,8 @@ __device__ __forceinline__ void acc_to_lds(const d4 (&acc)[Geo<NB>::NBLK], doubl
 struct CdParams {
     double lambda, alpha, tol;
     double la, l2;          // lambda * alpha, lambda * (1 - alpha): formed on the host so that they arrive in SGPRs
+    double two_la = 0.0, inv_two_la = 0.0;   // 2 la and 1 / (2 la): the register-resident sweeps work on a scaled state
+                                             // (insider_cd_reg.hpp); la > 0 there
     int max_sweeps;
     const uint8_t *order;   // [min(max_sweeps, INSIDER_PERM_PERIOD) + 1][ORDER_ROW], see k_order_table: sweep s reads row
                             // s mod INSIDER_PERM_PERIOD (include/insider_perm.h); the extra row is a copy of row 0 (look-ahead)
