@@ -22,7 +22,9 @@ namespace insider {
 
 constexpr int REG_ORDER_OFF = 128;   // byte offset of the block-offset dwords inside an order-table row
 static_assert(ORDER_ROW == 0x140, "the sweep prologue prefetches the next row at +0x140");
-constexpr int REG_BLOCK = 96;        // bytes between the code blocks of consecutive coordinates (see REG_BLOCK_HEAD)
+constexpr int REG_BLOCK = INSIDER_REG_BLOCK;   // bytes between the code blocks of consecutive coordinates (see REG_BLOCK_HEAD)
+#define REG_STR_(x) #x
+#define REG_STR(x) REG_STR_(x)
 
 // The sweep state in the SCALED form the step works on (round 3): with la = lambda alpha > 0
 //   y   = h / (2 la) + 1/2      h = Xty - offdiag(XtX) beta, the gradient part of src/coordinate_descent.cpp:94
@@ -54,13 +56,13 @@ struct RegState {
 // exec mask (the DPP fmacs that follow need every lane).  Same instruction count as narrowing the mask around the beta
 // update alone, but the part sustains a higher clock (round 3, tools/ab_variants.sh: +4 % sweep rate, bit-identical).
 #define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
-    ".org Lc%= + 96*" #KK "\n"                                   \
+    ".org Lc%= + " REG_STR(INSIDER_REG_BLOCK) "*" #KK "\n"       \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
     "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
     "v_max_f64 %[dn], %[" HS "], %[" HS "] clamp\n"              \
     "v_add_f64 %[dn], %[" HS "], -%[dn]\n"                       \
     "v_fma_f64 %[dn], -%[dn], %[" IS "], %[" BS "]\n"            \
-    "v_add_f64 %[" BS "], %[" BS "], -%[dn]\n"                   \
+    "v_fmac_f64 %[" BS "], -1.0, %[dn]\n"                        \
     "s_mov_b64 exec, -1\n"
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
 #define REG_BLOCK2_LO(KK) \
@@ -85,7 +87,7 @@ struct RegState {
     "s_setpc_b64 vcc\n"                            \
     ".p2align 12\n"                                \
     "Lc%=:\n"
-#define REG_EPILOGUE(NBLK) ".org Lc%= + 96*" #NBLK "\n s_waitcnt lgkmcnt(0)\n"   /* exit block */
+#define REG_EPILOGUE(NBLK) ".org Lc%= + " REG_STR(INSIDER_REG_BLOCK) "*" #NBLK "\n s_waitcnt lgkmcnt(0)\n"   /* exit block */
 #define REG_CLOBBERS                                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",   \
         "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",  \

@@ -357,10 +357,17 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
     return my_sweeps;
 }
 
+// bytes between the code blocks of consecutive coordinates in the register-resident sweep (insider_cd_reg.hpp).  A block is
+// 60 bytes long; 64-byte spacing (one instruction-cache line per block) measured the same as 96 (c3: 311 against 311-315
+// iterations/s), like the 128 ... 256-byte spacings of round 2: the cost of the computed jump is not the number of lines fetched
+#ifndef INSIDER_REG_BLOCK
+#define INSIDER_REG_BLOCK 96
+#endif
+
 // Order table, one row of ORDER_ROW bytes per sweep s < nsweeps: bytes [0, 64): the K coordinates in ascending key
 // order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
 // the row16 kernel, K <= 32); bytes [128, 320): 48 uint32, the code-block offsets of the register-resident kernel
-// (insider_cd_reg.hpp) as a successor list: dword 0 = 96 * (first coordinate of the sweep), dword 1 + k = 96 * (the
+// (insider_cd_reg.hpp) as a successor list: dword 0 = INSIDER_REG_BLOCK * (first coordinate of the sweep), dword 1 + k = INSIDER_REG_BLOCK * (the
 // coordinate visited after k), exit_block for the last one and for k >= K.  One thread per (sweep, coordinate): rank
 // by counting.
 __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
@@ -388,13 +395,13 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     if (l >= K) {
         row[l] = 0;
         if (l < 32) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
-        if (l < 47) blk[1 + l] = (uint32_t)exit_block * 96u;
+        if (l < 47) blk[1 + l] = (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
         return;
     }
     row[rank] = (uint8_t)l;
     if (rank < 32) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
-    if (l < 47) blk[1 + l] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * 96u : (uint32_t)exit_block * 96u;
-    if (rank == 0) blk[0] = (uint32_t)l * 96u;
+    if (l < 47) blk[1 + l] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * (uint32_t)INSIDER_REG_BLOCK : (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
+    if (rank == 0) blk[0] = (uint32_t)l * (uint32_t)INSIDER_REG_BLOCK;
 }
 
 // ---------------------------------------------------------------------------------------------
