@@ -4,7 +4,7 @@ bench.py times a bounded sample (G genes, one outer iteration, sweeps capped) an
 reference's formulation costs a fixed time per gene (row update, residual GEMMs, evaluation) plus a time per gene per
 coordinate sweep.  Here the same model is checked against
   * c2 (2000 x 20000, K = 20) IN FULL: 31 outer iterations, no sweep cap that bites, the reference's thread counts;
-  * c3 (10000 x 50000, K = 30): a 4096-gene slab, two outer iterations from the cold inits, effectively uncapped sweeps
+  * c3 (10000 x 50000, K = 30): a 2048-gene slab, one outer iteration from the cold inits, effectively uncapped sweeps
     (iteration 0 runs thousands of sweeps per gene, iteration 1 about a thousand).
 Writes one JSON (default gpurun_out/r03/cpu_model_check.json; copy to profiles/r03/): measured wall, the model's prediction
 for the same run from an independent sample, and their ratio.    python tools/cpu_validate.py [out.json] [c2|c3|both]"""
@@ -37,6 +37,16 @@ res = {"cpu_model": bench.cpu_model(), "nproc": cores, "row_threads": row_t, "co
                "gene-loop chunk 1, sweeps capped at 120) evaluated at the run's own genes / iterations / sweep count"}
 
 
+if os.path.exists(out_path):        # a run of one part keeps the other part's record
+    try:
+        old = json.load(open(out_path))
+        for k in ("c2_full", "c3_slab"):
+            if k in old:
+                res[k] = old[k]
+    except ValueError:
+        pass
+
+
 def model_for(name, lam, alpha, genes, iters, total_sweeps):
     m = bench.cpu_baseline(name, lam, alpha, cores, total_sweeps / max(genes * iters, 1), 12.0)["settings"]["reference_threads"]
     per_iter_s = genes * (m["fixed_ms_per_gene"] + m["sweep_ms_per_gene_sweep"] * total_sweeps / (genes * iters)) * 1e-3
@@ -61,9 +71,9 @@ if which in ("c2", "both"):
 
 if which in ("c3", "both"):
     n, p, _, _, K, lam, alpha, tuning, f = workloads.CONFIGS["c3"]
-    genes = 4096
+    genes = 2048
     w = workloads.make("c3", gene_range=(0, genes))
-    c_oracle.set_col_chunk(100)          # the reference's schedule(dynamic, 100): 41 chunks on the column threads
+    c_oracle.set_col_chunk(100)          # the reference's schedule(dynamic, 100): 21 chunks on the column threads
     t0 = time.perf_counter()
     r = c_oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, lam, lam, alpha, tuning=tuning, max_iter=1,
                           global_tol=-1.0, seed=20240301, row_threads=row_t, col_threads=col_t, max_sweeps=1000000)
@@ -73,7 +83,7 @@ if which in ("c3", "both"):
                       "sweeps_per_gene_per_iter": r["total_sweeps"] / (genes * r["iters"]), "measured_wall_s": wall,
                       "phase_seconds": r["phase_seconds"], "model_wall_s": pred, "measured_over_model": wall / pred,
                       "model_parameters": m,
-                      "note": "a 4096-gene slab is its own problem (its row factors see 4096 genes): the check is of the cost "
+                      "note": "a 2048-gene slab is its own problem (its row factors see 2048 genes): the check is of the cost "
                               "model at the run's own sweep count, not of the 50000-gene sweep count"}
     print("c3 slab:", json.dumps(res["c3_slab"]), flush=True)
     json.dump(res, open(out_path, "w"), indent=1)
