@@ -315,8 +315,7 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
             s_b[64 * u] = S.beta[u];
             s_w[64 * u] = w1;
         }
-        // (KMAX = 32 has no two registers to spare for the matrix unit's constant operand: vector form there)
-        const double dloss = KMAX <= 30 ? row16_sum_mfma(la * (acc1 + acc)) : row16_sum(la * (acc1 + acc));
+        const double dloss = row16_sum(la * (acc1 + acc));
         if (sweep > win) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);                   // wave-uniform, limited passes only
         const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
         if (cand != 0) {                                                                    // wave-uniform, rarely taken

@@ -43,6 +43,11 @@ struct ColFacArgs {
     // block of 16 levels); static per data set (mask and levels only)
     const uint8_t *cnt;
     int cnt_stride, cnt_off[CF_MAXC], nsteps;   // bytes per gene, offset of position t, ceil(tab_rows / 4)
+    // 1/2 n_j(l), the held-out entries of gene j in level l of the covariate at position t, as floats in the order the
+    // kernel's lanes want them: [block of 16 levels][l % 4][(l % 16) / 4] (lane quarter g4 reads the four levels g4 + 4 s
+    // of a block as one 16-byte word), zero beyond the last level; static per data set (k_half_counts)
+    const float *hn;
+    int hn_stride, hn_off[CF_MAXC];             // floats per gene, offset of position t
     // split solves (k_col_paircnt): the long genes' records are formed first, from their list, so that their solve can start
     // while the statistics of the others are still running; the launch over all genes then skips them
     const int *list;                      // gene ids of this launch (null: all genes 0 .. p-1)
@@ -54,7 +59,8 @@ struct ColFacArgs {
 // Gc = M + M' for the lower blocks, XtX_j = R'R - Gc; qc and the sum of squares go into row KP - 1 of the record
 // rtr: R'R (global, or a copy in LDS); qh / ss: this lane's Qheld entries (column 16 bj + c16) and the sum of squares,
 // loaded by the caller (early, so that their latency hides behind the MFMAs)
-template <int NB>
+// PREMASKED: rtr holds R'R inside the K x K part and zeros outside (the caller's LDS copy), so no index tests here
+template <int NB, bool PREMASKED = false>
 __device__ __forceinline__ void cf_store(d4 (&acc)[NB][NB], double *tr, const ColFacArgs &a, int j, int lane,
                                          const double *rtr, const double (&qh)[NB], double ss)
 {
@@ -75,7 +81,8 @@ __device__ __forceinline__ void cf_store(d4 (&acc)[NB][NB], double *tr, const Co
             for (int r = 0; r < 4; ++r) {
                 const int ra = 16 * bi + g4 + 4 * r, cb = 16 * bj + c16;
                 res[r] = acc[bi][bj][r] + tr[c16 * 17 + g4 + 4 * r];
-                if (ra < a.K && cb < a.K) res[r] = rtr[ra * KP + cb] - res[r];
+                if constexpr (PREMASKED) res[r] = rtr[ra * KP + cb] - res[r];   // outside K x K: -(0 + 0)
+                else if (ra < a.K && cb < a.K) res[r] = rtr[ra * KP + cb] - res[r];
             }
             wave_sync();
             if (bi == NB - 1 && g4 == 3) {   // global row KP - 1 = local row 15 = register 3 of lanes 48..63
@@ -200,27 +207,36 @@ __global__ void __launch_bounds__(WPB * 64) k_col_factored(ColFacArgs a)
 template <int NB>
 struct PairBlk {          // operands of one block of 16 levels, raw as fetched (nothing here waits for the loads)
     uint32_t cw[2];       // this lane's count bytes (k-step s = byte s)
-    double av[4][NB];     // factor rows: k-step s holds level min(l0 + 4 s + g4, L - 1), component 16 bb + c16
-    uint32_t gb[4], ge[4];   // group bounds of those levels
+    float4 hn;            // 1/2 n of levels l0 + 4 s + g4, s = 0 .. 3 (0 beyond the last level)
+    double av[4][NB];     // factor rows: k-step s holds level l0 + 4 s + g4, component 16 bb + c16
 };
 
+// Round 3: every vector instruction of this kernel costs f64-MFMA issue time (section 4 of DESIGN.md), and a block of 16 levels
+// used to spend ~75 of them around its 22 MFMAs (per-level address arithmetic with index clamps, group bounds -> counts ->
+// doubles, zero weights for the levels beyond the last, LDS reads of the table operand).  Now:
+//  * nothing is clamped or masked: rows beyond the covariate's last level are read as they come (the factor table has 16
+//    rows of zero padding after its last row; the rows in between belong to the next covariate and are finite) and meet
+//    EXACT ZEROS in P (their count bytes and their 1/2 n are zero), so they contribute nothing;
+//  * 1/2 n comes from a static float table laid out for one 16-byte load per lane and block (ColFacArgs::hn);
+//  * every address is a wave-uniform base (scalar arithmetic) plus a lane offset that never changes;
+//  * the table operand of the count product lives in registers for the whole gene (2 x nsteps doubles per lane).
 template <int NB, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
 {
     constexpr int KP = Geo<NB>::KP;
     extern __shared__ double s_cp[];   // per wave: 16 x 17 transpose scratch | R'R [KP][KP] | table rows [4 nsteps][KP], zero padded
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *tr = s_cp + (size_t)w * 16 * 17;
     double *rtr = s_cp + (size_t)WPB * 16 * 17;
     double *tabs = rtr + KP * KP;
-    for (int i = threadIdx.x; i < KP * KP; i += WPB * 64) rtr[i] = a.RtR[i];
+    for (int i = threadIdx.x; i < KP * KP; i += WPB * 64) rtr[i] = (i / KP < a.K && i % KP < a.K) ? a.RtR[i] : 0.0;
     for (int i = threadIdx.x; i < 4 * a.nsteps * KP; i += WPB * 64) {
         const int r = i / KP, k = i % KP;
         const int q = r < a.tab_skip_lo ? r : r + a.tab_skip_n;
         tabs[i] = r < a.tab_rows ? a.Astack[(size_t)q * KP + k] : 0.0;
     }
     __syncthreads();
-    int j = blockIdx.x * WPB + w;
+    int j = blockIdx.x * WPB + w;        // wave-uniform
     if (a.list) {
         if (j >= *a.list_count) return;
         j = a.list[j];
@@ -234,47 +250,42 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
     for (int bb = 0; bb < NB; ++bb) qh[bb] = a.Qheld[(size_t)j * KP + 16 * bb + c16];
     const double ss = a.yy_all[j] - a.yy_train[j];
     const int bpl = a.nsteps <= 4 ? 4 : 8;   // count bytes per lane and block
-    const double *tbl = tabs + g4 * KP + c16;   // B operand of k-step s, block bb: tbl[4 s KP + 16 bb]
+    // B operand of the count product, k-step s, block bb: table row 4 s + g4, component 16 bb + c16
+    double tb[CP_MAXSTEPS][NB];
+#pragma unroll
+    for (int s = 0; s < CP_MAXSTEPS; ++s)
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) tb[s][bb] = s < a.nsteps ? tabs[(4 * s + g4) * KP + 16 * bb + c16] : 0.0;
     d4 acc[NB][NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
         for (int bj = 0; bj < NB; ++bj) acc[bi][bj] = d4{0.0, 0.0, 0.0, 0.0};
     const uint8_t *cj = a.cnt + (size_t)j * a.cnt_stride;
+    const float *hj = a.hn + (size_t)j * a.hn_stride;
+    const unsigned off_c = (unsigned)lane * (unsigned)bpl, off_h = (unsigned)g4 * 4u, off_a = (unsigned)(g4 * KP + c16);
     for (int t = 0; t < a.c; ++t) {
-        const uint32_t *g = a.grp[t] + (size_t)j * (a.L[t] + 1);
         const int Lo = a.L[t];
         const bool cross = a.nlater[t] > 0;   // wave-uniform
         const uint8_t *ct = cj + a.cnt_off[t];
-        const double *At = a.Astack + (size_t)a.off[t] * KP + c16;
-        // every load is unconditional (clamped index, zero weight): conditional loads would be serialised by branches
+        const float *ht = hj + a.hn_off[t];
+        const double *At = a.Astack + (size_t)a.off[t] * KP;
         auto fetch = [&](int l0, PairBlk<NB> &b) {
             b.cw[0] = b.cw[1] = 0;
             if (cross) {
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)(l0 >> 4) * 64 + lane) * bpl);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + (size_t)(l0 >> 4) * 64 * bpl + off_c);
                 b.cw[0] = src[0];
                 if (bpl == 8) b.cw[1] = src[1];
             }
+            b.hn = *reinterpret_cast<const float4 *>(ht + l0 + off_h);
+            const double *Ab = At + (size_t)l0 * KP;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int l = l0 + 4 * s + g4;
-                const int lc = l < Lo ? l : Lo - 1;
-                b.gb[s] = g[lc];
-                b.ge[s] = g[lc + 1];
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int bb = 0; bb < NB; ++bb) b.av[s][bb] = At[(size_t)lc * KP + 16 * bb];
-            }
+                for (int bb = 0; bb < NB; ++bb) b.av[s][bb] = Ab[off_a + 4 * s * KP + 16 * bb];
         };
         // one block of 16 levels from its fetched operands
         auto compute = [&](int l0, PairBlk<NB> &cur) {
-            double hn[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {            // levels beyond the last: zero weight
-                const double keep = l0 + 4 * s + g4 < Lo ? 1.0 : 0.0;
-                hn[s] = keep * 0.5 * (double)(cur.ge[s] - cur.gb[s]);
-#pragma unroll
-                for (int bb = 0; bb < NB; ++bb) cur.av[s][bb] *= keep;
-            }
             d4 P[NB];
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) P[bb] = d4{0.0, 0.0, 0.0, 0.0};
@@ -285,9 +296,10 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
                         const double cv = (double)((cur.cw[s >> 2] >> (8 * (s & 3))) & 0xffu);
 #pragma unroll
                         for (int bb = 0; bb < NB; ++bb)
-                            P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv, tbl[4 * s * KP + 16 * bb], P[bb], 0, 0, 0);
+                            P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv, tb[s][bb], P[bb], 0, 0, 0);
                     }
             }
+            const double hn[4] = {(double)cur.hn.x, (double)cur.hn.y, (double)cur.hn.z, (double)cur.hn.w};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -314,7 +326,25 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
             }
         }
     }
-    cf_store<NB>(acc, tr, a, j, lane, rtr, qh, ss);
+    cf_store<NB, true>(acc, tr, a, j, lane, rtr, qh, ss);
+}
+
+// 1/2 n_j(l) in the kernel's order (ColFacArgs::hn); once per data set.  One thread per (gene, padded level).
+__global__ void __launch_bounds__(256) k_half_counts(ColFacArgs a, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)a.p * a.hn_stride) return;
+    const int j = (int)(i / a.hn_stride), r = (int)(i % a.hn_stride);
+    int t = 0;
+    while (t + 1 < a.c && r >= a.hn_off[t + 1]) ++t;
+    const int x = r - a.hn_off[t], blk = x >> 4, g4 = (x >> 2) & 3, sx = x & 3;
+    const int l = 16 * blk + 4 * sx + g4;
+    float v = 0.0f;
+    if (l < a.L[t]) {
+        const uint32_t *g = a.grp[t] + (size_t)j * (a.L[t] + 1);
+        v = 0.5f * (float)(g[l + 1] - g[l]);
+    }
+    out[i] = v;
 }
 
 // The dense pair counts of every gene (once per data set): one wave per gene, LDS histogram per covariate position.
@@ -400,7 +430,9 @@ __global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, in
             uint32_t cw[2] = {src[0], bpl == 8 ? src[1] : 0u};
             double part = 0.0;
 #pragma unroll
-            for (int s = 0; s < CP_MAXSTEPS; ++s) part = fma((double)((cw[s >> 2] >> (8 * (s & 3))) & 0xffu), vq[s], part);
+            for (int s = 0; s < CP_MAXSTEPS; ++s)
+                if (s < a.nsteps)   // wave-uniform: the table's k-steps only
+                    part = fma((double)((cw[s >> 2] >> (8 * (s & 3))) & 0xffu), vq[s], part);
             red[lane] = part;
             wave_sync();
             if (g4 == 0 && l0 + c16 < Lt) out[l0 + c16] = ((red[c16] + red[16 + c16]) + red[32 + c16]) + red[48 + c16];
@@ -418,16 +450,18 @@ __global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, in
             uint32_t cw[2] = {src[0], bpl == 8 ? src[1] : 0u};
             const double vv = l0 + c16 < Lp ? v[a.off[tp] + l0 + c16] : 0.0;
 #pragma unroll
-            for (int s = 0; s < CP_MAXSTEPS; ++s) acc[s] = fma((double)((cw[s >> 2] >> (8 * (s & 3))) & 0xffu), vv, acc[s]);
+            for (int s = 0; s < CP_MAXSTEPS; ++s)
+                if (s < a.nsteps) acc[s] = fma((double)((cw[s >> 2] >> (8 * (s & 3))) & 0xffu), vv, acc[s]);
         }
         const int qs = a.off[t];                                              // stacked index of level 0 of (t)
         const int c_lo = qs < a.tab_skip_lo ? qs : qs - a.tab_skip_n;          // its table column
 #pragma unroll
-        for (int s = 0; s < CP_MAXSTEPS; ++s) {
-            const double tot = row16_sum(acc[s]);
-            const int l = 4 * s + g4 - c_lo;
-            if (s < a.nsteps && c16 == 0 && l >= 0 && l < Lt) out[l] += tot;
-        }
+        for (int s = 0; s < CP_MAXSTEPS; ++s)
+            if (s < a.nsteps) {   // wave-uniform
+                const double tot = row16_sum(acc[s]);
+                const int l = 4 * s + g4 - c_lo;
+                if (c16 == 0 && l >= 0 && l < Lt) out[l] += tot;
+            }
         wave_sync();
     }
     wave_sync();

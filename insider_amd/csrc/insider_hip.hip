@@ -146,6 +146,7 @@ struct insider_hip_handle {
     double *Qheld = nullptr;          // p x KP workspace: sum_l A_l' Sheld[j][l]
     int col_factored = 1;             // option: factored column statistics (insider_col_factored.hpp): 0 list kernel, 1 cost model, 2 look-up form, 3 pair-count form
     uint8_t *cf_cnt = nullptr;        // dense pair counts of every gene (pair-count form), static per data set
+    float *cf_hn = nullptr;           // 1/2 held-out count per (gene, level) in the pair-count kernel's order (ColFacArgs::hn)
     bool cf_pair_ok = false;
     int cf_pos[CF_MAXC] = {0};        // position of covariate i in cf's order (decreasing level count)
     int row_counts = 1;               // option: k_gene_u from the dense pair counts when they exist
@@ -155,6 +156,10 @@ struct insider_hip_handle {
     int max_items = 0;
     bool merged = false;              // the merged masked row update is available (categorical covariates only)
     int row_merged = 1;               // option: use it
+    int row_gemm = 1;                 // option "row_gemm": weighted SYRK of a many-level covariate as one GEMM over genes (k_wgemm)
+    double *wg_part = nullptr;        // its per-slab partial sums
+    int wg_waves = 1024;              // option "row_gemm_waves": waves the GEMM is cut into (sets the number of gene slabs)
+    uint8_t *wg_pair = nullptr;       // packed pair index -> (a, b), a >= b: [2][16 ntile]
     int row_fused = 1;                // option "row_fused": level records' tail + equations + solve of the merged update in one launch
     double *sse_train = nullptr, *sse_test = nullptr, *b2 = nullptr, *b1 = nullptr, *loss_buf = nullptr, *stage = nullptr;
     int *sweeps = nullptr, *failflag = nullptr;
@@ -222,6 +227,10 @@ void free_workspace(insider_hip_handle *h)
                        &h->sc_part, &h->gram_part2, &h->sc_part2, &h->lvl_part, &h->lvl_sum, &h->lvl_sum_all, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->Qheld, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
                        &h->stage};
     for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
+    if (h->wg_part) (void)hipFree(h->wg_part);
+    if (h->wg_pair) (void)hipFree(h->wg_pair);
+    h->wg_part = nullptr;
+    h->wg_pair = nullptr;
     if (h->sweeps) (void)hipFree(h->sweeps);
     if (h->sweep_key) (void)hipFree(h->sweep_key);
     h->sweep_key = nullptr;
@@ -252,6 +261,35 @@ void free_workspace(insider_hip_handle *h)
     h->K = 0;
 }
 
+// The weighted SYRK of covariate i as a GEMM over genes (k_wgemm, insider_row_merged.hpp)?  Needs the static half-count table
+// of the pair-count statistics; pays when the covariate has at least four tiles of 16 levels and the GEMM needs clearly fewer
+// MFMAs than the per-(level, gene) form.
+struct WgPlan {
+    bool use = false;
+    int tiles = 0, LT = 0, zch = 0, ntile = 0, npair = 0, slab = 0, nslab = 0;
+};
+WgPlan wgemm_plan(const insider_hip_handle *h, int i, int K, bool whatever_the_option = false)
+{
+    WgPlan w;
+    if (!((h->row_gemm || whatever_the_option) && h->cf_pair_ok && h->cf_hn && h->merged && h->c <= CF_MAXC && K >= 1)) return w;
+    const int NB = (K + 1 + 15) / 16;
+    const int L = h->cov[i].L, NBLK = NB * (NB + 1) / 2;
+    w.tiles = cdiv(L, 16);
+    w.npair = K * (K + 1) / 2;
+    w.ntile = cdiv(w.npair, 16);
+    if (w.tiles < 4 || (double)w.tiles * w.ntile >= 0.9 * (double)L * NBLK) return w;
+    w.zch = cdiv(w.tiles, 7);
+    w.LT = cdiv(w.tiles, w.zch);
+    const int waves_per_slab = cdiv(w.ntile, 2) * w.zch;
+    // one wave per SIMD: the kernel runs beside the main stream's V -> u -> U'C chain (other waves fill the machine), its
+    // operands are prefetched a step ahead, and every slab costs a partial record (levels x pairs doubles) to write and re-read
+    const int want = std::max(1, std::min<int>(cdiv(h->wg_waves, waves_per_slab), (int)cdiv(h->p, 64)));
+    w.slab = (int)round_up(cdiv(h->p, want), 4);
+    w.nslab = (int)cdiv(h->p, w.slab);
+    w.use = true;
+    return w;
+}
+
 int ensure_workspace(insider_hip_handle *h, int K)
 {
     if (K < 1 || K > INSIDER_MAX_K) return fail(INSIDER_ERR_UNSUPPORTED, "K must be in 1..63");
@@ -271,9 +309,11 @@ int ensure_workspace(insider_hip_handle *h, int K)
     h->gram_blocks_n = cdiv(h->n, MM_SLAB);
     h->sc_blocks = cdiv(h->p, MM_SLAB);
     int rc;
-    if ((rc = dmalloc(&h->Astack, (size_t)h->SL * KP))) return rc;
+    // 16 rows of zero padding: the pair-count statistics kernel reads whole blocks of 16 levels without clamping
+    if ((rc = dmalloc(&h->Astack, (size_t)(h->SL + 16) * KP))) return rc;
+    HIPCHECK(hipMemset(h->Astack, 0, (size_t)(h->SL + 16) * KP * sizeof(double)));
     if ((rc = dmalloc(&h->R, (size_t)h->n * KP))) return rc;
-    if ((rc = dmalloc(&h->C, (size_t)std::max<int64_t>(h->p, h->ldp) * KP))) return rc;
+    if ((rc = dmalloc(&h->C, (size_t)(std::max<int64_t>(h->p, h->ldp) + 4) * KP))) return rc;   // + 4 zero rows: k_wgemm reads whole steps of four genes
     if ((rc = dmalloc(&h->RtR, (size_t)KP * KP))) return rc;
     if ((rc = dmalloc(&h->CCt, (size_t)KP * KP))) return rc;
     if ((rc = dmalloc(&h->Qfull, (size_t)h->p * KP))) return rc;
@@ -285,6 +325,28 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP + 2)))) return rc;
     if ((rc = dmalloc(&h->lvl_sum, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2)))) return rc;
     if (h->merged) {
+        // k_wgemm (weighted SYRK as a GEMM over genes): partial sums per gene slab, and the packed pair index -> (a, b) table
+        size_t wg_len = 0;
+        int wg_ntile = 0;
+        for (int i = 0; i < h->c; ++i) {
+            const WgPlan w = wgemm_plan(h, i, K, true);
+            if (w.use) {
+                wg_len = std::max(wg_len, (size_t)w.nslab * (16 * w.tiles) * (16 * w.ntile));
+                wg_ntile = w.ntile;
+            }
+        }
+        if (wg_len) {
+            if ((rc = dmalloc(&h->wg_part, wg_len))) return rc;
+            std::vector<uint8_t> ab((size_t)2 * 16 * wg_ntile, (uint8_t)(KP - 1));   // padded pairs: column KP - 1 of C, always zero
+            int idx = 0;
+            for (int a = 0; a < K; ++a)
+                for (int b = 0; b <= a; ++b, ++idx) {
+                    ab[idx] = (uint8_t)a;
+                    ab[(size_t)16 * wg_ntile + idx] = (uint8_t)b;
+                }
+            if ((rc = dmalloc(&h->wg_pair, ab.size()))) return rc;
+            HIPCHECK(hipMemcpy(h->wg_pair, ab.data(), ab.size(), hipMemcpyHostToDevice));
+        }
         const int LP = (int)round_up(std::max(h->max_L, 1), 2);
         if ((rc = dmalloc(&h->U, (size_t)h->p * LP))) return rc;
         if ((rc = dmalloc(&h->Ylvl, (size_t)std::max(h->max_L, 1) * KP))) return rc;
@@ -330,7 +392,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     h->have_perm = false;
     // rows of the padded factor buffers beyond K must stay zero: C rows are gathered with pitch KP and the
     // pad genes of the transposed layout index rows p..ldp-1
-    HIPCHECK(hipMemsetAsync(h->C, 0, (size_t)std::max<int64_t>(h->p, h->ldp) * KP * sizeof(double), h->stream));
+    HIPCHECK(hipMemsetAsync(h->C, 0, (size_t)(std::max<int64_t>(h->p, h->ldp) + 4) * KP * sizeof(double), h->stream));
     HIPCHECK(hipMemsetAsync(h->R, 0, (size_t)h->n * KP * sizeof(double), h->stream));
     HIPCHECK(hipMemsetAsync(h->failflag, 0, 4 * sizeof(int), h->stream));
     h->K = K;
@@ -575,6 +637,7 @@ int launch_col_stats(insider_hip_handle *h, bool timed, bool split = false)
         a.stat = h->stat_col;
         if (col_stats_path(h) == 2) {
             a.cnt = h->cf_cnt;
+            a.hn = h->cf_hn;
             if (split) {
                 // the long branch starts here: everything the main stream has produced so far (row factors, R'R, Qheld)
                 // plus what the side stream prepares for the solve (launch order, sweep-order table, Qfull)
@@ -888,6 +951,44 @@ int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
     return INSIDER_OK;
 }
 
+// level records' Gram part of covariate i: sum_j n_jl c_j c_j' for every level -> rec[l][0 .. STAT)
+int launch_level_gram(insider_hip_handle *h, int i, hipStream_t st, double *rec)
+{
+    const CovTables &ct = h->cov[i];
+    const WgPlan w = wgemm_plan(h, i, h->K);
+    if (w.use) {
+        const int stat_len = h->NB * (h->NB + 1) / 2 * 256, plen = stat_len + 2 * h->KP + 2;
+        const float *hn = h->cf_hn + h->cf.hn_off[h->cf_pos[i]];
+        const dim3 grid(cdiv(w.ntile, 8), w.nslab, w.zch);
+#define WG_LAUNCH(LT_)                                                                                                     \
+    hipLaunchKernelGGL((k_wgemm<LT_>), grid, dim3(256), 0, st, hn, h->cf.hn_stride, w.tiles, (const double *)h->C, h->KP,   \
+                       (int)h->p, w.slab, (const uint8_t *)h->wg_pair, w.ntile, h->wg_part)
+        switch (w.LT) {
+            case 4: WG_LAUNCH(4); break;
+            case 5: WG_LAUNCH(5); break;
+            case 6: WG_LAUNCH(6); break;
+            default: WG_LAUNCH(7); break;
+        }
+#undef WG_LAUNCH
+        KCHECK();
+        hipLaunchKernelGGL(k_wgemm_sum, dim3(cdiv(stat_len, 256), ct.L), dim3(256), 0, st, (const double *)h->wg_part, w.nslab,
+                           w.tiles, w.ntile, h->K, stat_len, rec, plen);
+        KCHECK();
+        return INSIDER_OK;
+    }
+    NB_DISPATCH(h->NB, {
+        constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
+        if (ct.nitems > 0)   // no held-out entry at all: every level sum is zero
+            hipLaunchKernelGGL((k_wsyrk<NB_, WPB_>), dim3(cdiv(ct.nitems, WPB_)), dim3(WPB_ * 64), 0, st,
+                               (const uint32_t *)ct.item_begin, (const uint32_t *)ct.item_end, ct.nitems,
+                               (const int *)ct.wl_idx, (const double *)ct.wl_w, (const double *)h->C, (int64_t)h->p, h->wpart);
+        hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), ct.L), dim3(256), 0, st, (const double *)h->wpart,
+                           (const int *)ct.lvl_item_ptr, STAT_, rec, PLEN);
+    });
+    KCHECK();
+    return INSIDER_OK;
+}
+
 // merged row update: the weighted SYRK + level sums of every covariate (they depend on C and the static lists only) on the
 // second side stream, from the point where C is final; row_update() waits for its covariate's event
 int launch_wsyrk_side(insider_hip_handle *h)
@@ -902,18 +1003,8 @@ int launch_wsyrk_side(insider_hip_handle *h)
     if (int rp = launch_mm_reduce_kp(h, h->Strain, h->SLP, h->C, (int)h->p, h->SL, h->sc_part2, h->SC, h->side3)) return rp;
     HIPCHECK(hipEventRecord(h->ev_prep, h->side3));
     for (int i = 0; i < h->c; ++i) {
-        const CovTables &ct = h->cov[i];
-        NB_DISPATCH(h->NB, {
-            constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
-            if (ct.nitems > 0)
-                hipLaunchKernelGGL((k_wsyrk<NB_, WPB_>), dim3(cdiv(ct.nitems, WPB_)), dim3(WPB_ * 64), 0, h->side2,
-                                   (const uint32_t *)ct.item_begin, (const uint32_t *)ct.item_end, ct.nitems,
-                                   (const int *)ct.wl_idx, (const double *)ct.wl_w, (const double *)h->C, (int64_t)h->p,
-                                   h->wpart);
-            hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), ct.L), dim3(256), 0, h->side2, (const double *)h->wpart,
-                               (const int *)ct.lvl_item_ptr, STAT_, h->lvl_sum_all + (size_t)h->lvl_off[i] * PLEN, PLEN);
-        });
-        KCHECK();
+        const int plen = h->NB * (h->NB + 1) / 2 * 256 + 2 * h->KP + 2;
+        if (int rg = launch_level_gram(h, i, h->side2, h->lvl_sum_all + (size_t)h->lvl_off[i] * plen)) return rg;
         HIPCHECK(hipEventRecord(h->ev_w[i], h->side2));
     }
     h->w_ready = true;
@@ -976,18 +1067,11 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
             HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[i], 0));
             HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
         }
+        if (!h->w_ready)
+            if (int rg = launch_level_gram(h, i, h->stream, h->lvl_sum)) return rg;
         NB_DISPATCH(h->NB, {
             constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
             double *rec = h->w_ready ? h->lvl_sum_all + (size_t)h->lvl_off[i] * PLEN : h->lvl_sum;
-            if (!h->w_ready) {
-                if (ct.nitems > 0)   // no held-out entry at all: every level sum is zero
-                    hipLaunchKernelGGL((k_wsyrk<NB_, WPB_>), dim3(cdiv(ct.nitems, WPB_)), dim3(WPB_ * 64), 0, h->stream,
-                                       (const uint32_t *)ct.item_begin, (const uint32_t *)ct.item_end, ct.nitems,
-                                       (const int *)ct.wl_idx, (const double *)ct.wl_w, (const double *)h->C, (int64_t)h->p,
-                                       h->wpart);
-                hipLaunchKernelGGL(k_level_sum, dim3(cdiv(STAT_, 16), L), dim3(256), 0, h->stream, (const double *)h->wpart,
-                                   (const int *)ct.lvl_item_ptr, STAT_, rec, PLEN);
-            }
             // the level records' tail, the level equations and (unless the equations still have to cross ranks) the solves: one launch
             fused_solve = h->world <= 1 && !h->force_allreduce && h->row_fused && NB_ <= 2;
             if (h->row_fused)
@@ -1224,6 +1308,7 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (h->Strain) (void)hipFree(h->Strain);
     if (h->Sheld) (void)hipFree(h->Sheld);
     if (h->cf_cnt) (void)hipFree(h->cf_cnt);
+    if (h->cf_hn) (void)hipFree(h->cf_hn);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
     if (h->side3) (void)hipStreamDestroy(h->side3);
@@ -1606,6 +1691,21 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
                     (void)hipFree(ovf);
                     fits = hv == 0;
                 }
+                if (fits && n < ((int64_t)1 << 24)) {   // (1/2 n as a float is exact)
+                    int hoff = 0;
+                    for (int t = 0; t < c; ++t) {
+                        cf.hn_off[t] = hoff;
+                        hoff += ((cf.L[t] + 15) / 16) * 16;
+                    }
+                    cf.hn_stride = hoff;
+                    CR(dmalloc(&h->cf_hn, (size_t)(p + 4) * hoff));   // + 4 zero rows: k_wgemm reads whole steps of four genes
+                    CH(hipMemsetAsync(h->cf_hn, 0, (size_t)(p + 4) * hoff * sizeof(float), h->stream));
+                    hipLaunchKernelGGL(k_half_counts, dim3((unsigned)cdiv((int64_t)p * hoff, 256)), dim3(256), 0, h->stream, cf,
+                                       h->cf_hn);
+                    CH(hipGetLastError());
+                } else {
+                    fits = false;
+                }
                 h->cf_pair_ok = fits;
             }
         }
@@ -1676,6 +1776,8 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "col_factored") h->col_factored = (int)value;   // 1 = cost model picks list / look-up / pair-count form (default), 2 = look-up form, 3 = pair-count form, 0 = k_list_stats
     else if (s == "row_counts") h->row_counts = (int)value;   // 1 = the merged row update takes u from the dense pair counts when they exist (default), 0 = from the entry lists
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
+    else if (s == "row_gemm_waves") { h->wg_waves = std::max(64, (int)value); h->K = 0; }   // (re-plans the workspace)
+    else if (s == "row_gemm") h->row_gemm = (int)value;       // 1 (default) = k_wgemm for covariates with >= 49 levels, 0 = k_wsyrk everywhere
     else if (s == "row_fused") h->row_fused = (int)value;     // 1 (default) = k_level_merged (one launch per covariate), 0 = k_level_pack / k_level_reduce / k_level_solve
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)

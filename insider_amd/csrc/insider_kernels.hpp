@@ -247,20 +247,9 @@ __device__ __forceinline__ double row16_sum(double v)
     return v;
 }
 
-// The same sum on the matrix unit: v_mfma_f64_4x4x4 works on four independent 4 x 4 blocks, one per 16-lane row; with B = 1 the
-// first product leaves the sums of four lanes in every lane, the second (its result as the A operand again) the sum of
-// those: two matrix instructions, which issue beside the other waves' vector instructions, instead of 12 vector ones.
-// Fixed summation order, the same in every lane.  (Layout checked on the device: tools/mfma_rowsum.hip.)
-__device__ __forceinline__ double row16_sum_mfma(double v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double r = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f64_4x4x4f64(r, 1.0, 0.0, 0, 0, 0);
-#else
-    return v;
-#endif
-}
-
+// (Not on the matrix unit: the contraction index of every f64 MFMA is lane / 16 — the DPP row number itself — and the four
+// blocks of v_mfma_f64_4x4x4 are 4-lane groups, so no chain of them adds up the 16 lanes of a row; checked on the device,
+// tools/mfma_rowsum.hip.)
 template <int W>
 __device__ __forceinline__ double group_sum(double v, int lane)
 {

@@ -272,6 +272,114 @@ k_wsyrk(const uint32_t *__restrict__ item_begin, const uint32_t *__restrict__ it
         for (int r = 0; r < 4; ++r) out[b * 256 + (sub + 4 * r) * 16 + c16] = acc[b][r];
 }
 
+// ---- the same weighted SYRK as ONE GEMM over genes (round 3; covariates with many levels) --------------------------------
+//   G_l[a][b] = sum_j n_jl c_ja c_jb = (N' P)[l][(a, b)],   N = [genes x levels] held-out counts, P = [genes x pairs], P_j(a, b) = c_ja c_jb
+// with the pairs a >= b packed densely (K (K + 1) / 2 of them, 16 per MFMA tile).  k_wsyrk spends NB (NB + 1) / 2 MFMAs on
+// every (level, four genes) — full padded 16 x 16 blocks — i.e. L x 3 per four genes at KP = 32; the GEMM needs
+// ceil(L / 16) x ceil(pairs / 16): 7 x 30 = 210 against 300 at c3 (K = 30, L = 100), 7 x 14 against 300 at K = 20.  And the
+// vector work around the MFMAs (which costs MFMA issue time in an f64 kernel) shrinks: per step of four
+// genes a wave converts LT counts and forms two products for 2 LT MFMAs, where k_wsyrk does ~8 instructions per 3 MFMAs.
+// The counts come as 1/2 n from the pair-count kernel's static float table (ColFacArgs::hn; the sum is doubled at the end).
+// Block = 4 waves = 4 x 2 pair tiles on the SAME gene slab (their count loads hit the same lines); grid.y = gene slabs,
+// grid.z = chunks of LT level tiles.  Padded genes (the table and C have four zero rows after the last gene) and padded pairs
+// (column KP - 1 of C, always zero) contribute exact zeros: no masks.  Partial sums per slab, added in slab order by
+// k_wgemm_sum (fixed order: reproducible), which also doubles them and writes the level records' blocks.
+template <int LT>
+__global__ void __launch_bounds__(256)
+k_wgemm(const float *__restrict__ hn, int hn_stride, int lt_total, const double *__restrict__ C, int KP, int p, int slab,
+        const uint8_t *__restrict__ pair_ab /*[2][16 ntile]*/, int ntile, double *__restrict__ part /*[slabs][16 lt_total][16 ntile]*/)
+{
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int T0 = (blockIdx.x * 4 + w) * 2;            // this wave's pair tiles T0, T0 + 1
+    if (T0 >= ntile) return;
+    const int lt0 = blockIdx.z * LT;                     // its level tiles lt0 .. lt0 + LT - 1 (beyond lt_total: skipped at the end)
+    const int g4 = lane >> 4, c16 = lane & 15;
+    const int j_begin = blockIdx.y * slab, j_end = j_begin + slab < p ? j_begin + slab : p;
+    // lane offsets in BYTES, fixed for the whole kernel: every load is a wave-uniform base + one of these (+ a constant)
+    unsigned off_a[2], off_b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int T = T0 + t < ntile ? T0 + t : ntile - 1;
+        off_a[t] = 8u * (unsigned)(g4 * KP + pair_ab[16 * T + c16]);
+        off_b[t] = 8u * (unsigned)(g4 * KP + pair_ab[16 * ntile + 16 * T + c16]);
+    }
+    const unsigned off_n = 4u * (unsigned)(g4 * hn_stride + (c16 & 3) * 4 + (c16 >> 2));   // level c16 of a tile, gene g4 of a step
+    d4 acc[LT][2];
+#pragma unroll
+    for (int l = 0; l < LT; ++l)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[l][t] = d4{0.0, 0.0, 0.0, 0.0};
+    struct Ops { float n[LT]; double ca[2], cb[2]; };
+    auto fetch = [&](int j0, Ops &o) {
+        const char *hb = reinterpret_cast<const char *>(hn + (size_t)j0 * hn_stride + 16 * lt0);
+        const char *cb = reinterpret_cast<const char *>(C + (size_t)j0 * KP);
+#pragma unroll
+        for (int l = 0; l < LT; ++l) o.n[l] = *reinterpret_cast<const float *>(hb + off_n + 64 * l);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            o.ca[t] = *reinterpret_cast<const double *>(cb + off_a[t]);
+            o.cb[t] = *reinterpret_cast<const double *>(cb + off_b[t]);
+        }
+    };
+    auto compute = [&](const Ops &o) {
+        double b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[t] = o.ca[t] * o.cb[t];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            const double a = (double)o.n[l];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[l][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[l][t], 0, 0, 0);
+        }
+    };
+    // two operand sets: the loads of the next four genes are in flight during the MFMAs of the current four
+    Ops o0, o1;
+    if (j_begin < j_end) fetch(j_begin, o0);
+    for (int j0 = j_begin; j0 < j_end; j0 += 8) {
+        if (j0 + 4 < j_end) fetch(j0 + 4, o1);
+        compute(o0);
+        if (j0 + 4 < j_end) {
+            if (j0 + 8 < j_end) fetch(j0 + 8, o0);
+            compute(o1);
+        }
+    }
+    double *out = part + (size_t)blockIdx.y * (16 * lt_total) * (16 * ntile);
+#pragma unroll
+    for (int l = 0; l < LT; ++l)
+        if (lt0 + l < lt_total) {   // wave-uniform
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (T0 + t < ntile) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out[(size_t)(16 * (lt0 + l) + g4 + 4 * r) * (16 * ntile) + 16 * (T0 + t) + c16] = acc[l][t][r];
+                }
+        }
+}
+
+// rec[l][e] for every entry e of the level record's lower 16 x 16 blocks: 2 sum_slabs part[slab][l][pair(a, b)] inside the
+// K x K part (slab order; pair(a, b) = hi (hi + 1) / 2 + lo, the packing of the table k_wgemm reads), 0 in the padding
+__global__ void __launch_bounds__(256) k_wgemm_sum(const double *__restrict__ part, int nslab, int lt_total, int ntile, int K,
+                                                   int stat_len, double *__restrict__ rec, int plen)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (e >= stat_len) return;
+    int blk = e >> 8, bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+    const int bj = blk - bi * (bi + 1) / 2;
+    const int a = 16 * bi + ((e >> 4) & 15), b = 16 * bj + (e & 15);
+    double s = 0.0;
+    if (a < K && b < K) {
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        const size_t stride = (size_t)(16 * lt_total) * (16 * ntile);
+        const double *src = part + (size_t)l * (16 * ntile) + (hi * (hi + 1) / 2 + lo);
+#pragma unroll 8
+        for (int sl = 0; sl < nslab; ++sl) s += src[(size_t)sl * stride];   // (loads batched by the unrolling, sums in slab order)
+        s *= 2.0;
+    }
+    rec[(size_t)l * plen + e] = s;
+}
+
 // the tail of a level's summed-partials record (see k_level_reduce): v = (U'C)[l], sum_{r in l} s_r from the
 // level-pair sample counts, and |l|.  Block = one level: 4 strided groups of stacked levels x 64 coordinates, the four
 // partial sums added in group order.

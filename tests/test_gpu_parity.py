@@ -397,6 +397,33 @@ def test_fused_level_kernel_is_bit_identical(K, levels):
         assert np.array_equal(runs[0]["row_matrices"][f"factor{i}"], runs[1]["row_matrices"][f"factor{i}"])
 
 
+@pytest.mark.parametrize("K,levels", [(7, (60, 3)), (20, (100, 10)), (30, (130, 7, 2)), (33, (64, 5))])
+def test_level_gram_as_gemm_matches_the_rank_one_form(oracle, K, levels):
+    """Covariates with many levels get their per-level weighted Gram sums sum_j n_jl c_j c_j' from ONE GEMM over genes
+    (k_wgemm: levels x packed index pairs, option row_gemm, default on) instead of one weighted rank-one update per (level,
+    gene) (k_wsyrk).  Same sums in another order: the fits agree to rounding, and both agree with the oracle."""
+    w = workloads.small(K=K, n=420, p=300, level_counts=levels, f=0.2, seed=90 + K)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.set_option("row_merged", 2)
+    runs = []
+    for gemm in (0, 1):
+        ds.set_option("row_gemm", gemm)
+        runs.append(ds.optimize(*_cp(w), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=4, seed=5))
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                          max_iter=4, seed=5)
+    for r in runs:
+        for i, a in enumerate(ref["row_matrices"]):
+            assert relerr(r["row_matrices"][f"factor{i}"], a) < 1e-7, i
+        assert relerr(r["column_factor"], ref["column_factor"]) < 1e-7
+        np.testing.assert_allclose(r["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-8, equal_nan=True)
+    for i in range(len(w.A0)):
+        assert relerr(runs[0]["row_matrices"][f"factor{i}"], runs[1]["row_matrices"][f"factor{i}"]) < 1e-9
+    # the two forms really are different code paths (another summation order)
+    assert not all(np.array_equal(runs[0]["row_matrices"][f"factor{i}"], runs[1]["row_matrices"][f"factor{i}"])
+                   for i in range(len(w.A0)))
+
+
 def test_sweep_counts_match_oracle(oracle):
     w = workloads.small(K=12, n=80, p=64)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)

@@ -1,4 +1,6 @@
-// Which chain of two v_mfma_f64_4x4x4 (4 blocks = the 4 DPP rows of a wave) sums the 16 lanes of each row?
+// Can a chain of two v_mfma_f64_4x4x4 add up the 16 lanes of each DPP row (the per-sweep loss change of the sweep kernel)?
+// Result on MI355X: NO, for all four operand orders: the contraction index is lane / 16 (the row number) and the four blocks
+// are 4-lane groups inside a row, so the products sum ACROSS rows.  The sweep kernel keeps its 4-step DPP reduction.
 // hipcc --offload-arch=gfx950 -O2 -o mfma_rowsum mfma_rowsum.hip && ./mfma_rowsum
 #include <hip/hip_runtime.h>
 #include <cstdio>
