@@ -332,15 +332,21 @@ k_wgemm(const float *__restrict__ hn, int hn_stride, int lt_total, const double 
             for (int t = 0; t < 2; ++t) acc[l][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[l][t], 0, 0, 0);
         }
     };
-    // two operand sets: the loads of the next four genes are in flight during the MFMAs of the current four
-    Ops o0, o1;
+    // three operand sets: the loads of the next TWO steps of four genes are in flight during the MFMAs of the current one (the
+    // kernel shares the machine with the main stream's memory-bound chain: one step of MFMAs does not cover a load's latency)
+    Ops o0, o1, o2;
     if (j_begin < j_end) fetch(j_begin, o0);
-    for (int j0 = j_begin; j0 < j_end; j0 += 8) {
-        if (j0 + 4 < j_end) fetch(j0 + 4, o1);
+    if (j_begin + 4 < j_end) fetch(j_begin + 4, o1);
+    for (int j0 = j_begin; j0 < j_end; j0 += 12) {
+        if (j0 + 8 < j_end) fetch(j0 + 8, o2);
         compute(o0);
         if (j0 + 4 < j_end) {
-            if (j0 + 8 < j_end) fetch(j0 + 8, o0);
+            if (j0 + 12 < j_end) fetch(j0 + 12, o0);
             compute(o1);
+            if (j0 + 8 < j_end) {
+                if (j0 + 16 < j_end) fetch(j0 + 16, o1);
+                compute(o2);
+            }
         }
     }
     double *out = part + (size_t)blockIdx.y * (16 * lt_total) * (16 * ntile);

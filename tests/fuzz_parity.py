@@ -22,7 +22,9 @@ for case in range(ncases):
     levels = tuple(int(x) for x in rng.integers(1, 13, size=c))
     if max(levels) == 1:
         levels = levels[:-1] + (3,)
-    n = int(rng.integers(max(16, max(levels) * 2), 260))
+    if rng.random() < 0.2:   # a many-level covariate: the GEMM form of the level Gram sums (k_wgemm) needs >= 49 levels
+        levels = (int(rng.choice([49, 64, 97, 130])),) + levels[1:]
+    n = int(rng.integers(max(16, max(levels) * 2), max(260, max(levels) * 3)))
     p = int(rng.integers(5, 140))
     K = int(rng.choice([1, 2, 3, 5, 8, 13, 15, 16, 17, 20, 23, 25, 30, 31, 32, 33, 40, 47, 48, 63]))
     tuning = int(rng.random() < 0.8)
@@ -32,7 +34,7 @@ for case in range(ncases):
     if c >= 2 and rng.random() < 0.25:
         kw["interaction_idx"] = (1, 2)
     opts = dict(row_merged=int(rng.choice([0, 1, 2])), col_factored=int(rng.choice([0, 1, 2, 3])),
-                cd_variant=int(rng.choice([0, 0, 0, 1, 2])), row_counts=int(rng.integers(0, 2)),
+                cd_variant=int(rng.choice([0, 0, 0, 1, 2])), row_counts=int(rng.integers(0, 2)), row_gemm=int(rng.integers(0, 2)),
                 # multi-pass column solves: first limit (0 = single pass), growth ratio, how many outer iterations use them
                 cd_pass1=int(rng.choice([0, 32, 48, 64])), cd_pass_ratio=int(rng.choice([2, 3, 4])),
                 cd_cold_iters=int(rng.choice([1, 3, 9])))
