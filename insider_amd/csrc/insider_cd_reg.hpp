@@ -7,11 +7,11 @@
 // 1/(XtX_kk + l2)) and holds columns i and 16 + i of the gene's Gram matrix in registers (2 x KMAX doubles, zero
 // diagonal).  All genes follow the same coordinate order (include/insider_perm.h), so the coordinate k of a step is
 // wave-uniform: the step is dispatched through a computed jump (s_setpc_b64) into a table of 96-byte code blocks,
-// one per coordinate, whose byte offsets the order table holds per sweep position (34 dwords loaded into SGPRs at
-// the start of a sweep, indexed with s_movrels).  Inside block k everything is static — the Gram operand is the register holding G[u][k], the lane that
+// one per coordinate, whose byte offsets the order table holds as a successor list (34 dwords loaded into SGPRs at
+// the start of a sweep; block k reads its successor from its own register).  Inside block k everything is static — the Gram operand is the register holding G[u][k], the lane that
 // owns k is k % 16, and its (negated) increment reaches the row as the DPP row_newbcast:k%16 source operand of a
-// 64-bit v_fmac_f64 (gfx90a+ "DP ALU DPP").  Per step and wave (4 genes): 7 vector + 4 scalar instructions, no
-// memory or LDS access; the sweep is one inline-asm block (the compiler turns a C++ switch into a compare tree with
+// 64-bit v_fmac_f64 (gfx90a+ "DP ALU DPP").  Per step and wave (4 genes): 6 vector + 4 scalar instructions (round 3: the
+// soft threshold is the hardware's output clamp on a scaled gradient, RegState below), no memory or LDS access; the sweep is one inline-asm block (the compiler turns a C++ switch into a compare tree with
 // register copies at the merge).  Without LDS the occupancy is set by registers alone (REG_WAVES(KMAX) waves per
 // SIMD), where the LDS-resident variant (insider_cd_row16.hpp) held 5 waves per CU at K = 30.
 // Measured on MI355X (tools/ubench3.hip): every VALU instruction of the block, including the DPP fmac and v_mov_b64,

@@ -4,9 +4,11 @@ TAG=${1:-r03}
 R=$(dirname $(dirname $(readlink -f $0)))
 S=$R/gpurun_out/$TAG; D=$R/profiles/$TAG
 mkdir -p $D
+# (gpurun merges new files INTO gpurun_out: remove the profile directories of earlier runs before calling tools/gpu_profile.sh,
+# or the PMC averages mix runs; the kernel-trace tools take the newest file of a directory)
 for f in bench_c1 bench_c2 bench_c3 bench_c3_grid bench_c3_s20w5 bench_c4 bench_c5 prof_c3 prof_c5; do cp $S/$f.json $D/ || exit 1; done
-cp $(ls $S/prof_c3/*/*kernel_stats.csv | tail -1) $D/c3_kernel_stats.csv
-cp $(ls $S/prof_c5/*/*kernel_stats.csv | tail -1) $D/c5_kernel_stats.csv
+cp $(ls -t $S/prof_c3/*/*kernel_stats.csv | head -1) $D/c3_kernel_stats.csv
+cp $(ls -t $S/prof_c5/*/*kernel_stats.csv | head -1) $D/c5_kernel_stats.csv
 cp $S/c3_steady_iteration_timeline.txt $S/slab8_split0.log $S/slab8_split2.log $S/slab8_timeline_split0.txt $S/slab8_timeline_split2.txt $D/
 python3 $R/tools/pmc_csv.py $S/pmc_fetch $S/pmc_write > $D/c3_pmc_summary.csv
 python3 $R/tools/trace_avg.py $S/prof_c3 > $D/c3_trace_avg.txt 2>&1

@@ -3,7 +3,8 @@ An outer iteration starts with the row phase's first kernel (k_mm_rows<4, true>:
 with the last sweep-kernel launch of its column step.    python tools/iter_timeline.py DIR [iterations back from the end]"""
 import csv, glob, sys
 d = sys.argv[1]; back = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
+import os
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)   # the newest run in the directory
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void insider::", "").replace("insider::", "")[:44], r["Queue_Id"]) for r in rows)
 starts, seen_cd = [], True
@@ -28,3 +29,19 @@ print("iteration span us %.1f (first row-phase kernel to the end of the column s
 qs = sorted(set(e[3] for e in it))
 for e in it:
     print("%9.1f %9.1f %8.1f q%d %s" % ((e[0] - t0) / 1e3, (e[1] - t0) / 1e3, (e[1] - e[0]) / 1e3, qs.index(e[3]), e[2]))
+
+# means over the steady-state iterations of the run's last call (all but its first five)
+per = []
+for k in range(len(starts) - 1):
+    seg = ev[starts[k]:starts[k + 1]]
+    st = [e for e in seg if e[2].startswith(("k_col_paircnt", "k_col_factored", "k_list_stats"))]
+    cd = [e for e in seg if e[2].startswith("k_cd_cols_reg") and ", false>" not in e[2]]
+    if not st or not cd:
+        continue
+    per.append(((st[-1][0] - seg[0][0]) / 1e3, (st[-1][1] - st[-1][0]) / 1e3, (cd[-1][1] - cd[0][0]) / 1e3,
+                (ev[starts[k + 1]][0] - seg[0][0]) / 1e3, len(cd)))
+steady = [x for x in per[-26:] if x[4] == 1]
+if steady:
+    m = [sum(x[i] for x in steady) / len(steady) for i in range(4)]
+    print("steady-state means over %d iterations (us): row phase (to the start of the column statistics) %.1f, statistics %.1f, "
+          "sweeps %.1f, iteration period %.1f" % (len(steady), m[0], m[1], m[2], m[3]))

@@ -1,6 +1,7 @@
 """Print a rocprofv3 --stats kernel summary (kernel_stats.csv) sorted by total time."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)   # the newest run in the directory
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f, "total GPU ms", tot / 1e6)
