@@ -165,7 +165,9 @@ struct insider_hip_handle {
     int *sweeps = nullptr, *failflag = nullptr;
     int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sched_bucket)
     unsigned long long *sweep_total = nullptr;
-    uint8_t *order = nullptr;
+    uint8_t *order = nullptr;          // the sweep-order table the next column solve reads: one of order_buf
+    uint8_t *order_buf[2] = {nullptr, nullptr};   // two tables: the next outer iteration's is built while the current solve runs
+    hipEvent_t ev_tab = nullptr;
     int order_rows = 0;
     // gene scheduling for the CD kernel: genes sorted by the sweep count of their previous solve
     int *gene_perm = nullptr;
@@ -236,7 +238,7 @@ void free_workspace(insider_hip_handle *h)
     h->sweep_key = nullptr;
     if (h->failflag) (void)hipFree(h->failflag);
     if (h->sweep_total) (void)hipFree(h->sweep_total);
-    if (h->order) (void)hipFree(h->order);
+    for (auto &b : h->order_buf) { if (b) (void)hipFree(b); b = nullptr; }
     h->order = nullptr;
     h->order_rows = 0;
     for (void *q : {(void *)h->gene_perm, (void *)h->sched_cnt[0], (void *)h->sched_cnt[1], (void *)h->sched_rank, (void *)h->sched_bkt, (void *)h->sched_long, (void *)h->cd_hsave,
@@ -512,22 +514,29 @@ struct Timer {   // HIP-event pair around one launch on the library's stream (op
     }
 };
 
+// Builds the sweep-order table of outer iteration `iter` into order_buf[slot] (on `stream`); the caller makes it current
+// (h->order) when its solve is launched.  Two buffers: an outer iteration's table depends on (seed, iter) only, so the NEXT one
+// is built while the current solve runs — the sweep kernel leaves no room for other waves, so the builder runs in its tail,
+// on SIMDs that have already drained — instead of competing with the row phase.
 int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode,
-                       hipStream_t stream = nullptr)
+                       hipStream_t stream = nullptr, int slot = 0)
 {
     if (!stream) stream = h->stream;
     // one period of the order sequence at most (include/insider_perm.h): the table does not grow with max_sweeps
     const int rows = std::min<int64_t>(max_sweeps, INSIDER_PERM_PERIOD);
     if (h->order_rows < rows) {
-        if (h->order) (void)hipFree(h->order);
-        h->order = nullptr;
-        int rc = dmalloc(&h->order, (size_t)(rows + 4) * ORDER_ROW);   // + the look-ahead row (and the prologue's touch of the one after)
-        if (rc) return rc;
+        for (auto &b : h->order_buf) {
+            if (b) (void)hipFree(b);
+            b = nullptr;
+            int rc = dmalloc(&b, (size_t)(rows + 4) * ORDER_ROW);   // + the look-ahead row (and the prologue's touch of the one after)
+            if (rc) return rc;
+        }
         h->order_rows = rows;
     }
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)(rows + 1) * 64, 256)), dim3(256), 0, stream, seed, iter, K, rows,
-                       order_mode, K * 8, reg_kmax(K), h->order);
+                       order_mode, K * 8, reg_kmax(K), h->order_buf[slot]);
     KCHECK();
+    if (!h->order) h->order = h->order_buf[slot];
     return INSIDER_OK;
 }
 
@@ -1322,6 +1331,7 @@ void insider_hip_destroy(insider_hip_handle *h)
     for (auto e : h->ev_w) (void)hipEventDestroy(e);
     if (h->ev_cd_done) (void)hipEventDestroy(h->ev_cd_done);
     if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
+    if (h->ev_tab) (void)hipEventDestroy(h->ev_tab);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1392,6 +1402,7 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     for (auto &e : h->ev_w) CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
     CH(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
+    CH(hipEventCreateWithFlags(&h->ev_tab, hipEventDisableTiming));
     // ---- X (gene-major lines of pitch ldn) and mask codes -------------------------------------------------
     CR(dmalloc(&h->X, (size_t)p * h->ldn));
     CR(dmalloc(&h->codes, (size_t)p * h->ldn));
@@ -1863,15 +1874,21 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
         // ---- column step (:365-378) -------------------------------------------------------------------------------
         if ((rc = phase_R(h, true, true))) return rc;
         const int checkpoint = iter % 10 == 0;
-        if (alpha != 0.0 && iter == 0)   // later iterations: prepared on the side stream right after the previous solve
-            if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
+        if (alpha != 0.0 && iter == 0)   // later iterations: built on the side stream while the previous solve ran
+            if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode, nullptr, 0))) return rc;
         if (masked) if ((rc = launch_col_stats(h, true, use_split(h, masked, alpha, (int)iter)))) return rc;
-        if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true, (int)iter, true))) return rc;  // :376
         if (alpha != 0.0) {
-            if (iter < max_iter)
-                if ((rc = ensure_order_table(h, seed, iter + 1, K, h->max_sweeps, h->order_mode, h->side))) return rc;
-            if ((rc = side_close(h))) return rc;
+            h->order = h->order_buf[iter & 1];
+            if (iter < max_iter) {   // the next iteration's table, from here on: beside this iteration's solve
+                HIPCHECK(hipEventRecord(h->ev_tab, h->stream));
+                HIPCHECK(hipStreamWaitEvent(h->side, h->ev_tab, 0));
+                if ((rc = ensure_order_table(h, seed, iter + 1, K, h->max_sweeps, h->order_mode, h->side, (int)((iter + 1) & 1))))
+                    return rc;
+            }
         }
+        if ((rc = launch_col_solve(h, masked, true, lambda2, alpha, sub_tol * decay, checkpoint, true, (int)iter, true))) return rc;  // :376
+        if (alpha != 0.0)
+            if ((rc = side_close(h))) return rc;
         if (checkpoint) {                                                                       // :381-408
             if ((rc = launch_test_sse(h, masked, true))) return rc;
             pre_loss = loss;
@@ -2050,8 +2067,10 @@ int insider_hip_optimize_col(insider_hip_handle *h, double *const *A, double *C,
     if ((rc = ensure_workspace(h, K))) return rc;
     if ((rc = upload_factors(h, A, C, K))) return rc;
     if ((rc = phase_R(h))) return rc;
-    if (alpha != 0.0)
-        if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode))) return rc;
+    if (alpha != 0.0) {
+        if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode, nullptr, 0))) return rc;
+        h->order = h->order_buf[0];
+    }
     if (tuning == 1) if ((rc = launch_col_stats(h, false))) return rc;
     HIPCHECK(hipMemsetAsync(h->failflag + 2, 0, 2 * sizeof(int), h->stream));
     if ((rc = launch_col_solve(h, tuning, true, lambda, alpha, tol, 0, false))) return rc;
