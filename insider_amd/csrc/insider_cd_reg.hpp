@@ -520,6 +520,15 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
 #endif
                 a.sweeps[w.j] = sweeps;
                 if (a.sweep_bins) atomicAdd(&a.sweep_bins[blockIdx.x & 255], (unsigned long long)sweeps);
+                if (a.sched_key) {   // first half of the next solve's launch order (k_sched_bucket's arithmetic), spread over the solve
+                    int k = a.sched_key[w.j];
+                    const int s16 = sweeps * 16;
+                    k = a.sched_reset ? s16 : (k + s16) / 2;
+                    a.sched_key[w.j] = k;
+                    const int b = sched_bucket(k, 0);
+                    a.sched_bkt[w.j] = (uint16_t)b;
+                    a.sched_rank[w.j] = atomicAdd(&a.sched_cnt[b], 1);
+                }
             }
         }
         return;

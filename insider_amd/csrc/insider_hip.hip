@@ -549,12 +549,14 @@ int long_cap(const insider_hip_handle *h)
 
 // the launch order of the next column solve: genes by decreasing key, a bucket sort on a log scale (insider_kernels.hpp).
 // sweeps != null: the keys are first updated from the last solve's sweep counts (reset: replaced, else smoothed)
-int launch_gene_order(insider_hip_handle *h, const int *sweeps, int reset, int float_bits, hipStream_t st)
+// bucketed: the solve kernel has already done k_sched_bucket's part (ColArgs::sched_key ...), with the same counter set
+int launch_gene_order(insider_hip_handle *h, const int *sweeps, int reset, int float_bits, hipStream_t st, bool bucketed = false)
 {
     int *cnt = h->sched_cnt[h->sched_flip], *cnt_next = h->sched_cnt[h->sched_flip ^ 1];
     h->sched_flip ^= 1;
-    hipLaunchKernelGGL(k_sched_bucket, dim3(cdiv(h->p, 256)), dim3(256), 0, st, sweeps, (int)h->p, reset, float_bits,
-                       h->sweep_key, cnt, h->sched_bkt, h->sched_rank);
+    if (!bucketed)
+        hipLaunchKernelGGL(k_sched_bucket, dim3(cdiv(h->p, 256)), dim3(256), 0, st, sweeps, (int)h->p, reset, float_bits,
+                           h->sweep_key, cnt, h->sched_bkt, h->sched_rank);
     KCHECK();
     hipLaunchKernelGGL(k_sched_scatter, dim3(cdiv(h->p, 256)), dim3(256), 0, st, (const int *)cnt, cnt_next,
                        (const uint16_t *)h->sched_bkt, (const int *)h->sched_rank, (int)h->p, h->gene_perm, long_cap(h),
@@ -698,7 +700,7 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
     Timer t;
     int rc = t.begin(h, timed);
     if (rc) return rc;
-    bool eval_after = false;
+    bool eval_after = false, fused_bucket = false;
     ColArgs eval_args;
     if (alpha == 0.0) {
         RidgeArgs a;
@@ -779,6 +781,9 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         a.pass_slot = nullptr;
         a.bucket_cnt = nullptr;
         a.cap_hits = solve ? h->failflag + 2 : nullptr;
+        a.sched_key = a.sched_cnt = a.sched_rank = nullptr;
+        a.sched_bkt = nullptr;
+        a.sched_reset = 0;
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
         // the register-resident kernel scales its state by 1 / (2 lambda alpha): lambda alpha = 0 (alpha < 0 or lambda = 0: no l1
         // term at all) takes the group kernel below
@@ -789,6 +794,14 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
             // index, the genes still running save their state and an estimate of their remaining length (from the decay
             // of the loss change), k_pass_scatter groups them by that estimate, and the next pass continues them
             // bit-identically in waves of similar length (insider_cd_reg.hpp).  A pass with nothing left exits at once.
+            if (solve) {   // every gene's part of the next launch order, when it finishes (launch_gene_order below skips k_sched_bucket)
+                a.sched_key = h->sweep_key;
+                a.sched_cnt = h->sched_cnt[h->sched_flip];
+                a.sched_rank = h->sched_rank;
+                a.sched_bkt = h->sched_bkt;
+                a.sched_reset = (outer_iter < insider_hip_handle::EARLY || !h->have_perm) ? 1 : 0;
+                fused_bucket = true;
+            }
             int limits[16], npass = 0;
             if (solve && outer_iter >= 0 && outer_iter < h->cd_cold_iters && h->cd_pass_first >= 32)
                 for (int64_t l = h->cd_pass_first; l < std::min<int64_t>(h->max_sweeps, 4 * (int64_t)INSIDER_PERM_PERIOD) && npass < 16;
@@ -860,7 +873,7 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
             HIPCHECK(hipStreamWaitEvent(h->side, h->ev_cd_done, 0));
             st = h->side;
         }
-        if ((rc = launch_gene_order(h, h->sweeps, (outer_iter < insider_hip_handle::EARLY || !h->have_perm) ? 1 : 0, 0, st)))
+        if ((rc = launch_gene_order(h, h->sweeps, (outer_iter < insider_hip_handle::EARLY || !h->have_perm) ? 1 : 0, 0, st, fused_bucket)))
             return rc;
         h->have_perm = true;
         if (early) {

@@ -685,6 +685,11 @@ struct ColArgs {
     int *cap_hits;               // [0] counter of the genes a solve stopped at max_sweeps without convergence (the reference has no
                                  // cap, src/coordinate_descent.cpp:86-114), [1] the longest solve: insider_hip_get_info("cap_hits" /
                                  // "max_gene_sweeps"); may be null
+    // launch order of the NEXT solve, first half (what k_sched_bucket does), done by the register-resident solve kernel itself
+    // when a gene finishes: key update from its sweep count, bucket, rank inside the bucket.  null: not fused
+    int *sched_key, *sched_cnt, *sched_rank;
+    uint16_t *sched_bkt;
+    int sched_reset;
 };
 
 constexpr int CD_BUCKETS = 192;                  // 8 per octave of the estimate (1 .. 2^20 sweeps), longest first
