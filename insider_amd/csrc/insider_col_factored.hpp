@@ -409,13 +409,14 @@ __global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, in
     const int j = blockIdx.x * WPB + w;
     if (j >= a.p) return;
     double *v = s_uc + (size_t)w * (SL + LP + WAVE), *out = v + SL, *red = out + LP;
-    for (int q = lane; q < SL; q += WAVE) v[q] = V[(size_t)j * SLP + q];
+    const int Lt = a.L[t];
+    // the gene's row of V, without the covariate's own columns (never read: u sums over the OTHER covariates)
+    for (int q = lane; q < SL; q += WAVE) v[q] = (q < a.off[t] || q >= a.off[t] + Lt) ? V[(size_t)j * SLP + q] : 0.0;
     for (int l = lane; l < LP; l += WAVE) out[l] = 0.0;
     wave_sync();
     const int g4 = lane >> 4, c16 = lane & 15;
     const int bpl = a.nsteps <= 4 ? 4 : 8;
     const uint8_t *cj = a.cnt + (size_t)j * a.cnt_stride;
-    const int Lt = a.L[t];
     if (a.nlater[t] > 0) {   // its own table: rows = its levels, columns = table rows of the later covariates
         double vq[CP_MAXSTEPS];
 #pragma unroll

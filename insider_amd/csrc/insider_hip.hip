@@ -357,6 +357,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
         if ((rc = dmalloc(&h->gram_part2, (size_t)std::max(h->gram_blocks_p, h->gram_blocks_n) * KP * KP))) return rc;
         if ((rc = dmalloc(&h->sc_part2, (size_t)h->sc_blocks * h->SL * KP))) return rc;
         if ((rc = dmalloc(&h->Vlev, (size_t)h->p * h->SLP))) return rc;
+        HIPCHECK(hipMemsetAsync(h->Vlev, 0, (size_t)h->p * h->SLP * sizeof(double), h->stream));   // (columns are filled as they are first needed)
         if ((rc = dmalloc(&h->Qheld, (size_t)h->p * KP))) return rc;
     }
     if ((rc = dmalloc(&h->eq, (size_t)h->max_L * (KP * KP + KP)))) return rc;
@@ -936,9 +937,15 @@ int launch_gene_v(insider_hip_handle *h, int q_begin, int q_end)
 {
     // V[:, q_begin:q_end) = C A[q_begin:q_end, :]'  (A given "transposed": one row per output column)
     const int N = q_end - q_begin;
-    hipLaunchKernelGGL((k_mm_rows<4, true>), dim3(cdiv(cdiv((int)h->p, 16), 4), cdiv(N, 64)), dim3(256), 0, h->stream,
-                       (const double *)h->C, (int64_t)h->KP, (int)h->p, h->K, (const double *)(h->Astack + (size_t)q_begin * h->KP),
-                       h->KP, N, h->Vlev + q_begin, (int64_t)h->SLP, N);
+    if (N <= 0) return INSIDER_OK;
+#define GV_LAUNCH(NT_)                                                                                                        \
+    hipLaunchKernelGGL((k_mm_rows<NT_, true>), dim3(cdiv(cdiv((int)h->p, 16), 4), cdiv(N, 16 * NT_)), dim3(256), 0, h->stream, \
+                       (const double *)h->C, (int64_t)h->KP, (int)h->p, h->K,                                                \
+                       (const double *)(h->Astack + (size_t)q_begin * h->KP), h->KP, N, h->Vlev + q_begin, (int64_t)h->SLP, N)
+    if (N <= 16) GV_LAUNCH(1);        // (a covariate with few levels: one 16-column tile, not four)
+    else if (N <= 32) GV_LAUNCH(2);
+    else GV_LAUNCH(4);
+#undef GV_LAUNCH
     KCHECK();
     return INSIDER_OK;
 }
@@ -1873,7 +1880,13 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
         if (use_merged(h, masked)) { if ((rc = launch_wsyrk_side(h))) return rc; }                // incl. the row prep
         else if ((rc = launch_row_prep(h, masked))) return rc;                                  // :332
         if (masked && !use_merged(h, masked)) if ((rc = launch_row_stats(h, true))) return rc;
+        // V = C A' of the covariates 1 .. c-1: what covariate 0's update reads.  Covariate 0's own columns are first read by
+        // covariate 1's update, after they have been recomputed from the updated factors (below): not formed here
+#ifdef INSIDER_V_ALL   // (A/B builds: every column, as before round 3)
         if (use_merged(h, masked)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
+#else
+        if (use_merged(h, masked)) if ((rc = launch_gene_v(h, h->c > 1 ? h->lvl_off[1] : h->SLcat, h->SLcat))) return rc;
+#endif
         for (int i = 0; i < h->c; ++i) {
             const bool need_R = !use_merged(h, masked) || i + 1 == h->c;
             if ((rc = row_update(h, i, -1, masked, lambda1, need_R))) return rc;                // :339

@@ -1,5 +1,5 @@
 """Print the kernel timeline of one steady-state outer iteration from a rocprofv3 kernel trace (per queue).
-An outer iteration starts with the row phase's first kernel (k_mm_rows<4, true>: V = C A') after a column solve and ends
+An outer iteration starts with the row phase's first kernel (k_mm_rows<.., true>: V = C A') after a column solve and ends
 with the last sweep-kernel launch of its column step.    python tools/iter_timeline.py DIR [iterations back from the end]"""
 import csv, glob, sys
 d = sys.argv[1]; back = int(sys.argv[2]) if len(sys.argv) > 2 else 6
@@ -11,7 +11,7 @@ starts, seen_cd = [], True
 for i, e in enumerate(ev):
     if e[2].startswith("k_cd_cols_reg"):
         seen_cd = True
-    elif e[2].startswith("k_mm_rows<4, true>") and seen_cd:
+    elif e[2].startswith("k_mm_rows<") and ", true>" in e[2] and seen_cd:   # V = C A' (any tile count): the row phase's first kernel
         starts.append(i)
         seen_cd = False
 a, b = starts[-back - 1], starts[-back]
