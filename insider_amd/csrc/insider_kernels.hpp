@@ -1074,8 +1074,10 @@ __global__ void __launch_bounds__(256) k_sum_partials(const double *__restrict__
     const int ol = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int o = blockIdx.x * 16 + ol;
     double s = 0.0;
-    if (o < len)
+    if (o < len) {
+#pragma unroll 8   // eight loads in flight, summed in the same order: a chain of single loads takes ~3 us each beside the row phase's kernels
         for (int b = g; b < nblk; b += 16) s += part[(size_t)b * len + o];
+    }
     red[g][ol] = s;
     __syncthreads();
     if (g == 0 && o < len) {
@@ -1205,8 +1207,10 @@ __global__ void __launch_bounds__(256) k_level_sum(const double *__restrict__ pa
     const int o = blockIdx.x * 16 + ol, l = blockIdx.y;
     const int c0 = lvl_chunk_ptr[l], c1 = lvl_chunk_ptr[l + 1];
     double s = 0.0;
-    if (o < len)
+    if (o < len) {
+#pragma unroll 8   // (loads in flight together, same summation order: see k_sum_partials)
         for (int ch = c0 + g; ch < c1; ch += 16) s += part[(size_t)ch * len + o];
+    }
     red[g][ol] = s;
     __syncthreads();
     if (g == 0 && o < len) {

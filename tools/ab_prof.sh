@@ -11,9 +11,14 @@ spec=$1; shift
 n=${spec%%:*}; f=${spec#*:}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-pass-failed -mllvm -amdgpu-mfma-vgpr-form=1"
 /opt/rocm/bin/hipcc $FLAGS $f -o $OUT/lib_$n.so insider_amd/csrc/insider_hip.hip -L/opt/rocm/lib -lrccl > $OUT/build_$n.log 2>&1 || { tail $OUT/build_$n.log; exit 1; }
+i=0
 for v in default $n default $n default $n; do
+  i=$((i + 1))
   if [ $v = default ]; then unset INSIDER_HIP_LIB; else export INSIDER_HIP_LIB=$OUT/lib_$v.so; fi
-  rm -rf $OUT/prof_$v
-  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_$v -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/prof_$v.json 2> $OUT/prof_$v.err)
-  echo "$v: $(python3 -c "import json; print('value %.1f' % json.loads(open('$OUT/prof_$v.json').readline())['value'])") $(python3 tools/iter_timeline.py $OUT/prof_$v | tail -1 | cut -d: -f2-)"
+  D=$OUT/prof_${v}_$i
+  rm -rf $D
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $R/bench.py --no-cpu-baseline "$@" > $D.json 2> $D.err)
+  python3 tools/iter_timeline.py $D > $D.timeline.txt 2>&1
+  echo "$v ($i): $(python3 -c "import json; print('value %.1f' % json.loads(open('$D.json').readline())['value'])") $(tail -1 $D.timeline.txt | cut -d: -f2-)"
+  rm -rf $D   # (the traces are 10 MB each: the timeline text is what is kept)
 done

@@ -11,7 +11,9 @@ starts, seen_cd = [], True
 for i, e in enumerate(ev):
     if e[2].startswith("k_cd_cols_reg"):
         seen_cd = True
-    elif e[2].startswith("k_mm_rows<") and ", true>" in e[2] and seen_cd:   # V = C A' (any tile count): the row phase's first kernel
+    elif seen_cd and (e[2].startswith("k_wgemm<") or e[2].startswith("k_wsyrk<") or
+                      (e[2].startswith("k_mm_rows<") and ", true>" in e[2]) or e[2].startswith("k_mm_reduce<")):
+        # the row phase's first kernel: a level Gram GEMM, C'C or V = C A', whichever stream wins
         starts.append(i)
         seen_cd = False
 a, b = starts[-back - 1], starts[-back]
