@@ -17,6 +17,9 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 t0 = time.time()
+# FUZZ_ONLY=<case>: run that case alone (same random stream), FUZZ_OPTS="name=value,...": with these options on top of its own
+only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None
+extra = dict((k, float(v)) for k, v in (kv.split("=") for kv in os.environ.get("FUZZ_OPTS", "").split(",") if kv))
 for case in range(ncases):
     c = int(rng.integers(1, 5))
     levels = tuple(int(x) for x in rng.integers(1, 13, size=c))
@@ -51,6 +54,8 @@ for case in range(ncases):
         continue   # a level that never occurs: not a valid data set
     rs = np.random.default_rng(seed)
     scale = float(rng.choice([0.001, 0.3]))
+    if only is not None and case != only:
+        continue   # (every draw of the case has been made: the stream of the later cases is unchanged)
     A = [np.asfortranarray(rs.standard_normal(a.shape) * scale) for a in w.A0]
     C = np.asfortranarray(rs.standard_normal(w.C0.shape) * scale)
     Z = None
@@ -58,6 +63,7 @@ for case in range(ncases):
         Z = np.asfortranarray(rs.standard_normal((w.n, m)))
         A = A + [np.asfortranarray(rs.standard_normal((m, w.K)) * scale)]
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
+    opts.update(extra)
     for k, v in opts.items():
         ds.set_option(k, v)
     ds.set_option("max_sweeps", 300)
@@ -89,6 +95,9 @@ for case in range(ncases):
             tol_traj = 1e-7         # of this regime just outside 1e-6 / 1e-8: factors 1.2e-6, trajectories 1.4e-8 and 1.6e-8.)
         if not (e_row < tol and e_col < tol and e_traj < tol_traj and got["iters"] == ref["iters"]):
             msg = f"row {e_row:.2e} col {e_col:.2e} traj {e_traj:.2e} iters {got['iters']} vs {ref['iters']}"
+    if only is not None and got is not None:
+        print(f"case {case}: row {e_row:.2e} col {e_col:.2e} traj {e_traj:.2e} iters {got['iters']} vs {ref['iters']} "
+              f"sweeps oracle {ref.get('total_sweeps')} opts {opts}", flush=True)
     if msg:
         bad += 1
         print(f"MISMATCH case {case}: {kw} opts {opts} iters {iters} seed {seed} scale {scale} m {m} sub_tol {sub_tol}: {msg}", flush=True)
