@@ -442,19 +442,22 @@ int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M
 }
 
 // part[slab][L][KP] = sum over slabs of MM_SLAB rows of X[m][l] Y[m][n], then the fixed-order sum over slabs -> out[L][KP]
+// out == nullptr: the partial sums are left in `part` for the consumer to add up (k_level_merged); returns the slab count in *nslab
 int launch_mm_reduce_kp(insider_hip_handle *h, const double *X, int64_t ldx, const double *Y, int M, int L, double *part,
-                        double *out, hipStream_t st = nullptr)
+                        double *out, hipStream_t st = nullptr, int *nslab = nullptr)
 {
     if (!st) st = h->stream;
     const int slabs = cdiv(M, MM_SLAB);
+    if (nslab) *nslab = slabs;
     NB_DISPATCH(h->NB, {
         (void)WPB_;
         hipLaunchKernelGGL((k_mm_reduce<NB_>), dim3(slabs, cdiv(L, 16)), dim3(64), 0, st, X, ldx, Y, (int64_t)h->KP, M,
                            MM_SLAB, L, h->KP, part, h->KP);
     });
     KCHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(L * h->KP, 16)), dim3(256), 0, st, (const double *)part, slabs,
-                       L * h->KP, out);
+    if (out)
+        hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(L * h->KP, 16)), dim3(256), 0, st, (const double *)part, slabs,
+                           L * h->KP, out);
     KCHECK();
     return INSIDER_OK;
 }
@@ -1090,8 +1093,13 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
                                h->SLcat, h->U);
         }
         KCHECK();
-        // Y = U'C, the same reduction over genes as (S C')
-        if (int rcy = launch_mm_reduce_kp(h, h->U, LP, h->C, (int)h->p, L, h->sc_part, h->Ylvl)) return rcy;
+        // Y = U'C, the same reduction over genes as (S C'); with the fused level kernel its per-slab partial sums are added up
+        // there (k_sum_partials' order), which takes one launch per covariate off the main chain
+        int ypart_n = 0;
+        if (int rcy = launch_mm_reduce_kp(h, h->U, LP, h->C, (int)h->p, L, h->sc_part, h->row_fused ? nullptr : h->Ylvl, nullptr,
+                                          &ypart_n))
+            return rcy;
+        if (!h->row_fused) ypart_n = 0;
         if (h->w_ready) {   // wsyrk + level sums came from side2, C'C and (S^train C') from side3
             HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[i], 0));
             HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
@@ -1105,7 +1113,7 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
             fused_solve = h->world <= 1 && !h->force_allreduce && h->row_fused && NB_ <= 2;
             if (h->row_fused)
                 hipLaunchKernelGGL((k_level_merged<NB_>), dim3(L), dim3(256), 0, h->stream, (const double *)rec,
-                                   (const double *)h->Ylvl, (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
+                                   (const double *)(ypart_n ? h->sc_part : h->Ylvl), ypart_n, (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
                                    (const int *)(h->lvl_count_all + h->lvl_off[i]), (const double *)h->CCt,
                                    (const double *)(h->SC + (size_t)row0 * KP), L, h->K, lambda1, fused_solve ? 1 : 0, h->eq,
                                    h->Astack + (size_t)row0 * KP, h->failflag);

@@ -416,9 +416,12 @@ __global__ void __launch_bounds__(256) k_level_pack(const double *__restrict__ Y
 // 0..3 form sum_{r in l} s_r from the level-pair sample counts (k_level_pack's sum, same order); wave 0 then builds the
 // level's normal equations exactly as k_level_reduce does (eq is still written: the gene-sharded path all-reduces it) and,
 // with do_solve, solves them as k_level_solve does — same arithmetic on the same values, bit-identical results.
+// Y: (U'C)[l], or — ypart_n > 0 — its per-slab partial sums part[slab][L][KP] straight from k_mm_reduce: the block then adds
+// them up itself, in k_sum_partials' order (16 strided groups, then the groups in order: the same bits), which takes that
+// kernel and its launch off the main chain of the row phase.
 template <int NB>
 __global__ void __launch_bounds__(256) k_level_merged(const double *__restrict__ rec /*[L][STAT + 2 KP + 2]: weighted-SYRK level sums*/,
-                                                      const double *__restrict__ Y /*[L][KP]*/,
+                                                      const double *__restrict__ Y /*[L][KP]*/, int ypart_n,
                                                       const double *__restrict__ paircnt /*[L][SL]*/, int SL,
                                                       const double *__restrict__ Astack, const int *__restrict__ lvl_count,
                                                       const double *__restrict__ CCt, const double *__restrict__ SC /*rows of this covariate*/,
@@ -430,8 +433,19 @@ __global__ void __launch_bounds__(256) k_level_merged(const double *__restrict__
     __shared__ double s_H[KP * KP];
     __shared__ double s_A[NB <= 2 ? KP * KP : 1];   // the in-kernel solve is the register route (K <= 31); larger K: k_level_solve
     __shared__ double s_s[KP];
+    __shared__ double s_y[16][KP];
     const int l = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     if (l >= L) return;
+    if (ypart_n > 0) {   // wave-uniform.  k_sum_partials: s_m = sum_{b = m, m + 16, ...} part[b][o], then sum_m s_m in order
+        const size_t len = (size_t)L * KP;
+        for (int c = threadIdx.x; c < 16 * KP; c += 256) {
+            const int m = c / KP, o = c % KP;
+            double sm = 0.0;
+#pragma unroll 8
+            for (int b = m; b < ypart_n; b += 16) sm += Y[(size_t)b * len + (size_t)l * KP + o];
+            s_y[m][o] = sm;
+        }
+    }
     double ss = 0.0;
     if (lane < K)
         for (int q = g; q < SL; q += 4) ss = fma(paircnt[(size_t)l * SL + q], Astack[(size_t)q * KP + lane], ss);
@@ -441,7 +455,15 @@ __global__ void __launch_bounds__(256) k_level_merged(const double *__restrict__
     const bool valid = lane < K;
     const int sub = lane >> 4, c16 = lane & 15;
     const double cnt = (double)lvl_count[l];
-    const double v = valid ? Y[(size_t)l * KP + lane] : 0.0;
+    double v = 0.0;
+    if (valid) {
+        if (ypart_n > 0) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v += s_y[m][lane];
+        } else {
+            v = Y[(size_t)l * KP + lane];
+        }
+    }
     const double ssum = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
     const double *src = rec + (size_t)l * (STAT + 2 * KP + 2);
     d4 h[NBLK];
