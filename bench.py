@@ -80,13 +80,10 @@ def cpu_model():
 
 
 def source_sha():
-    """Hash of the device / host sources a profile was taken on: profiles/traffic.json carries the same hash."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "insider_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the sources on disk (insider_amd/_build.py: csrc/, include/, compiler flags).  The library carries the hash
+    of the sources it was compiled from; profiles/traffic.json carries the hash of the library its counters were taken on."""
+    from insider_amd import _build
+    return _build.source_sha()
 
 
 def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
@@ -353,6 +350,8 @@ def main():
         mfma_tflops = mfma_gene * p_loc * 2048.0 / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py), valid for the
         # sources they were taken on
+        from insider_amd import _lib as ilib
+        lib_sha = ilib.library_source_sha()           # what the loaded binary says it was compiled from
         traffic, tnote = {}, "no profiles/traffic.json entry for this workload"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -360,18 +359,36 @@ def main():
                 tj = json.load(open(tpath))
                 ent = tj.get(name, {})
                 if ent and world == 1:
-                    same = tj.get("source_sha") == source_sha()
-                    traffic = ent
+                    # valid only for the library it was measured on: compared with the hash the LOADED library reports
+                    same = tj.get("source_sha") == lib_sha
+                    traffic = ent if same else {}
                     tnote = (f"rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, {tj.get('command', '?')}); FETCH x 2 per "
-                             f"MI355X_MICROARCH.md; sources {'IDENTICAL to' if same else 'DIFFER from'} this run's "
-                             f"(source_sha {tj.get('source_sha')}, commit {tj.get('commit', '?')})")
+                             f"MI355X_MICROARCH.md; taken on source_sha {tj.get('source_sha')} (commit {tj.get('commit', '?')}), "
+                             + ("the sources of the library that ran here" if same else
+                                f"NOT the library that ran here ({lib_sha}): traffic withheld (null)"))
             except Exception as e:
                 tnote = f"profiles/traffic.json unreadable: {e!r}"
         tr_stats = traffic.get("col_stats_bytes_per_launch")
         tr_cd = traffic.get("cd_bytes_per_launch")
         tr_col = (tr_stats + tr_cd) if (tr_stats is not None and tr_cd is not None) else None
+        # issue-slot counters of the sweep / statistics kernels (tools/pmc_issue.sh -> profiles/issue.json), same validity rule
+        issue, inote = {}, "no profiles/issue.json entry for this workload"
+        ipath = os.path.join(ROOT, "profiles", "issue.json")
+        if os.path.exists(ipath) and world == 1:
+            try:
+                ij = json.load(open(ipath))
+                if name in ij:
+                    if ij.get("source_sha") == lib_sha:
+                        issue = ij[name]
+                        inote = f"rocprofv3 --pmc SQ_* passes ({ij.get('command', '?')}), source_sha {ij.get('source_sha')} = the library that ran here"
+                    else:
+                        inote = f"profiles/issue.json was taken on source_sha {ij.get('source_sha')}, not on the library that ran here ({lib_sha}): withheld"
+            except Exception as e:
+                inote = f"profiles/issue.json unreadable: {e!r}"
         st_cd, st_col = ds.info("cd_ms_steady"), (ds.info("col_stats_ms_steady") if tuning == 1 else 0.0)
         cd_updates = prof["sweeps"] * K
+        cd_issue = issue.get("sweep_kernel", {})
+        cd_clock = 1e9 * cd_issue["clock_GHz"] if cd_issue.get("clock_GHz") else 2.4e9
         out = {
             "metric": f"outer-iterations/sec (masked INSIDER fit, {n} x {p_total}, K={K})",
             "value": slabs * args.steps / dt, "unit": "outer-iterations/s", "n_gpus": world, "steps": args.steps,
@@ -411,6 +428,7 @@ def main():
                 "kernel": kern, "bound": "mfma", "achieved": mfma_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": mfma_tflops / FP64_PEAK_TFLOPS, "avg_launch_ms": gram_ms, "launches": prof["col_stats_launches"],
                 "mfma_f64_16x16x4_per_gene": mfma_gene,
+                "issue_counters": issue.get("statistics_kernel") or None,
                 "traffic": tr_stats,
                 "hbm_GBs_measured": tr_stats / (gram_ms * 1e-3) / 1e9 if (tr_stats and gram_ms > 0) else None,
                 "hbm_frac_measured": tr_stats / (gram_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (tr_stats and gram_ms > 0) else None,
@@ -428,16 +446,22 @@ def main():
                           # useful arithmetic: a coordinate update is K fused multiply-adds on the gene's gradient (+ O(1))
                           "fp64_tflops_useful": cd_updates * 2.0 * K / max(prof["cd_ms"] * 1e-3, 1e-9) / 1e12,
                           "fp64_vector_frac": cd_updates * 2.0 * K / max(prof["cd_ms"] * 1e-3, 1e-9) / 1e12 / FP64_PEAK_TFLOPS,
-                          # the builder's own issue model (7 VALU per 4-gene coordinate step at the nominal 2.4 GHz): a
-                          # how-close-to-this-design's-ceiling figure, not a hardware roofline
-                          "valu_issue_model_updates_per_s": 1024 * 4 * 2.4e9 / (7 * 4),
-                          "valu_issue_model_frac": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * 2.4e9 / (7 * 4)),
+                          # issue model of this design: 6 VALU instructions (4 cycles each) per 4-gene coordinate step and SIMD,
+                          # 1024 SIMDs, at the clock the part held during the counter passes (GRBM_GUI_ACTIVE / 8 / kernel time;
+                          # 2.4 GHz nominal when no counters are on file): how close the kernel is to ITS ceiling, not a hardware
+                          # roofline.  valu_busy_measured = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles of the kernel (rocprofv3 --pmc)
+                          "valu_issue_model_updates_per_s": 1024 * 4 * cd_clock / (6 * 4),
+                          "valu_issue_model_frac": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * cd_clock / (6 * 4)),
+                          "valu_issue_model_clock_GHz": cd_clock / 1e9,
+                          "valu_busy_measured": cd_issue.get("valu_busy_of_resident_simd_time"),
+                          "issue_counters": cd_issue or None, "issue_counters_note": inote,
                           "share_of_wall": prof["cd_ms"] / (dt * 1e3),
                           # the reference's sweep loop has no cap (src/coordinate_descent.cpp:86-114): solves this call ended
                           # at the library's max_sweeps without convergence (must be 0), and the longest solve
                           "cap_hits": int(ds.info("cap_hits")), "max_gene_sweeps": int(ds.info("max_gene_sweeps")),
                           "max_sweeps": int(ds.info("max_sweeps"))},
             "loss": res["loss"], "train_rmse": res["train_rmse"], "test_rmse": res["test_rmse"], "options": args.opt,
+            "library_source_sha": lib_sha, "sources_on_disk_sha": source_sha(),
             "setup_s": {"generate": t_gen, "upload_and_precompute": t_up},
         }
         if world > 1:      # the same problem on ONE GPU, from this repository's own single-GPU run (not measured in this job)

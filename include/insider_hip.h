@@ -57,6 +57,8 @@ typedef struct insider_hip_handle insider_hip_handle;
  * the stream, reducing, and synchronising again.  Return 0 on success. */
 typedef int (*insider_allreduce_fn)(void *user, double *dev_buf, int64_t count, void *stream);
 
+/* "insider_hip <version> (gfx950) src:<sha16>": the hash is over the sources the library was compiled from
+ * (insider_amd/csrc, include/, compiler flags; insider_amd/_build.py), so a caller can tell which sources a number belongs to. */
 const char *insider_hip_version(void);
 const char *insider_hip_last_error(void);
 /* Number of visible HIP devices (0 if none); does not create a context. */
@@ -250,7 +252,8 @@ int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out);
 
 /* Diagnostics: copy an internal per-gene array to the host: "cd_pass_slot" (uint32 x p: what the last limited pass of a
  * multi-pass column solve left per gene: 0xFFFFFFFF = finished, else estimate bucket << 24 | rank), "gene_perm" (int32 x p:
- * the launch order). */
+ * the launch order), "order_table" (the sweep-order table of the last column solve: rows of 320 bytes, one per sweep of the
+ * period; bytes 0..K-1 of row s = the coordinates of sweep s in visiting order, include/insider_perm.h). */
 int insider_hip_get_array(insider_hip_handle *h, const char *name, void *out, int64_t bytes);
 
 /* Diagnostics: per-gene sweep counts of the last column update (p ints), and the HIP-event time in ms of the

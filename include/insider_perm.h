@@ -49,7 +49,9 @@ INSIDER_HD uint32_t insider_h32(uint32_t x)
  * sweep s mod PERIOD.  A solve that long has seen 16384 fresh uniformly random orders; what the period buys is a
  * sweep-order table of fixed size on the device (PERIOD rows per outer iteration), so that the number of sweeps of a solve
  * needs no cap — the reference's loop has none (src/coordinate_descent.cpp:86-114). */
+#ifndef INSIDER_PERM_PERIOD   /* (tests/test_gpu_period.py builds library AND oracle with 64u to cross the wrap cheaply) */
 #define INSIDER_PERM_PERIOD 16384u
+#endif
 
 /* Per-(seed, iteration, sweep) base word; uniform across coordinates and genes. */
 INSIDER_HD uint32_t insider_perm_base(uint64_t seed, uint32_t iter, uint32_t sweep)

@@ -44,6 +44,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.environ.get("INSIDER_HIP_LIB"):
+        # the in-tree library must be THE build of the sources on disk: compared by content hash (the library carries the
+        # hash of what it was compiled from), never by mtime; a stale or missing binary is rebuilt, not run
+        from . import _build
+        if _build.needs_build(LIB_PATH):
+            try:
+                _build.build_library()
+            except Exception as e:
+                raise InsiderError(ERR_NO_DEVICE, f"{LIB_PATH} is missing or was built from other sources (library "
+                                                  f"{_build.library_sha(LIB_PATH)}, sources {_build.source_sha()}) and the "
+                                                  f"rebuild failed: {e!r} (there is no CPU fallback)")
     if not os.path.exists(LIB_PATH):
         raise InsiderError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
                                           f"g.build()'` (there is no CPU fallback)")
@@ -89,6 +100,12 @@ def load():
     lib.insider_hip_last_cd_ms.restype = C.c_double
     _lib = lib
     return lib
+
+
+def library_source_sha():
+    """The source hash the LOADED library reports (insider_hip_version(): 'src:<sha16>')."""
+    v = load().insider_hip_version().decode()
+    return v.rsplit("src:", 1)[1] if "src:" in v else None
 
 
 def check(status):

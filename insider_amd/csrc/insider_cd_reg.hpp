@@ -55,21 +55,30 @@ struct RegState {
 // The four scalar-like instructions of a step do useful work on the owner lane of each row only: they run under a four-lane
 // exec mask (the DPP fmacs that follow need every lane).  Same instruction count as narrowing the mask around the beta
 // update alone, but the part sustains a higher clock (round 3, tools/ab_variants.sh: +4 % sweep rate, bit-identical).
+// The address add sits between the clamp and the subtraction that depends on it (round 4: in the shadow of the clamp's
+// result latency instead of in front of the chain, sweep kernel 2.08 -> 2.00 ms per launch at c3, tools/exp_probe.sh).
+// Measured and NOT adopted in round 4 (same tool): the head on all lanes with the beta update as a bank-masked
+// DPP fmac on a lane indicator (no exec writes: slower, 2.17-2.24 ms — four more full-width fp64 instructions per step
+// cost more clock than the two exec writes cost issue slots); wave priorities by hardware wave id (slower); the exec
+// narrowing after the clamp (slower); other positions of the add (equal).
 #define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
-    ".org Lc%= + " REG_STR(INSIDER_REG_BLOCK) "*" #KK "\n"       \
+    REG_ORG(KK)                                                  \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
-    "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
     "v_max_f64 %[dn], %[" HS "], %[" HS "] clamp\n"              \
+    "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
     "v_add_f64 %[dn], %[" HS "], -%[dn]\n"                       \
     "v_fma_f64 %[dn], -%[dn], %[" IS "], %[" BS "]\n"            \
     "v_fmac_f64 %[" BS "], -1.0, %[dn]\n"                        \
     "s_mov_b64 exec, -1\n"
+#define REG_JUMP "s_setpc_b64 vcc\n"
+#define REG_ORG(KK) ".org Lc%= + " REG_STR(INSIDER_REG_BLOCK) "*" #KK "\n"
+#define REG_ALIGN "s_setpc_b64 vcc\n.p2align 12\n"
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
 #define REG_BLOCK2_LO(KK) \
-    REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) "s_setpc_b64 vcc\n"
+    REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) REG_JUMP
 #define REG_BLOCK2_HI(KK, IT) \
-    REG_BLOCK_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) "s_setpc_b64 vcc\n"
-#define REG_BLOCK1(KK) REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) "s_setpc_b64 vcc\n"
+    REG_BLOCK_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) REG_JUMP
+#define REG_BLOCK1(KK) REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_JUMP
 #define REG_PROLOGUE                               \
     "s_load_dwordx16 s[64:79], %[tb], 0x0\n"       \
     "s_load_dwordx16 s[80:95], %[tb], 0x40\n"      \
@@ -84,10 +93,9 @@ struct RegState {
     "s_load_dword %[p1], %[tb], 0x180\n"           /* its three lines are in the scalar cache when that sweep */ \
     "s_load_dword %[p2], %[tb], 0x1c0\n"           /* starts; waited for in the exit block                    */ \
     "s_add_u32 vcc_lo, s64, s98\n"                 \
-    "s_setpc_b64 vcc\n"                            \
-    ".p2align 12\n"                                \
+    REG_ALIGN                                      \
     "Lc%=:\n"
-#define REG_EPILOGUE(NBLK) ".org Lc%= + " REG_STR(INSIDER_REG_BLOCK) "*" #NBLK "\n s_waitcnt lgkmcnt(0)\n"   /* exit block */
+#define REG_EPILOGUE(NBLK) REG_ORG(NBLK) " s_waitcnt lgkmcnt(0)\n"   /* exit block */
 #define REG_CLOBBERS                                                                                                     \
     "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",   \
         "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",  \
@@ -127,7 +135,7 @@ struct RegState {
                        [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2)                                   \
                      : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(      \
                            S.tau[0]),                                                                                    \
-                       [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm)                                                    \
+                       [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm)                                         \
                      : REG_CLOBBERS);                                                                                    \
     }
 #else

@@ -1309,7 +1309,10 @@ int check_factor_args(insider_hip_handle *h, double *const *A, const double *C, 
 // =================================================================================================================
 extern "C" {
 
-const char *insider_hip_version(void) { return "insider_hip 0.2.0 (gfx950)"; }
+#ifndef INSIDER_SOURCE_SHA
+#define INSIDER_SOURCE_SHA "unknown-source-sha"   /* __graft_entry__.build() passes the hash of csrc/ + include/ (insider_amd/_build.py) */
+#endif
+const char *insider_hip_version(void) { return "insider_hip 0.4.0 (gfx950) src:" INSIDER_SOURCE_SHA; }
 
 const char *insider_hip_last_error(void) { return g_err.c_str(); }
 
@@ -2369,6 +2372,7 @@ int insider_hip_get_array(insider_hip_handle *h, const char *name, void *out, in
     int64_t have = 0;
     if (s == "cd_pass_slot") { src = h->cd_pass_slot; have = h->p * (int64_t)sizeof(int); }
     else if (s == "gene_perm") { src = h->gene_perm; have = h->p * (int64_t)sizeof(int); }
+    else if (s == "order_table") { src = h->order; have = (int64_t)(h->order_rows + 1) * ORDER_ROW; }   // rows of ORDER_ROW bytes: the last solve's
     else return fail(INSIDER_ERR_ARG, "unknown array " + s);
     if (!src || bytes > have) return fail(INSIDER_ERR_ARG, "array not available or too short");
     HIPCHECK(hipSetDevice(h->device));

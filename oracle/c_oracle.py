@@ -6,7 +6,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libinsider_oracle.so")
+# INSIDER_ORACLE_LIB: another build of the same oracle (tests/test_gpu_period.py: INSIDER_PERM_PERIOD = 64 on both sides)
+_SO = os.environ.get("INSIDER_ORACLE_LIB") or os.path.join(_HERE, "_build", "libinsider_oracle.so")
 TRAJ_STRIDE = 10
 TRAJ_COLS = ("iter", "train_rmse", "test_rmse", "sse_half", "row_reg_half", "col_reg_half", "l1_reg", "loss",
              "delta_loss", "decay")
@@ -16,6 +17,8 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds)."""
+    if os.environ.get("INSIDER_ORACLE_LIB"):
+        return _SO
     deps = [os.path.join(_HERE, "insider_oracle.c"), os.path.join(_HERE, "Makefile"),
             os.path.join(os.path.dirname(_HERE), "include", "insider_perm.h")]   # the sweep-order spec is shared with the HIP side
     if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(d) for d in deps):
@@ -48,6 +51,22 @@ def set_col_chunk(chunk=100):
     """OpenMP chunk of the per-gene loops (reference: schedule(dynamic, 100), src/optimize.cpp:213,243).  A bounded gene
     sample needs chunk 1 to occupy every thread; results do not depend on it (genes are independent)."""
     lib().oracle_set_col_chunk(C.c_int(int(chunk)))
+
+
+_sink = None
+
+
+def set_sweep_sink(p=None):
+    """Test diagnostic: per-gene sweep counts of the LAST column step of the following calls land in the returned int32
+    array (None switches it off)."""
+    global _sink
+    if p is None:
+        lib().oracle_set_sweep_sink(None)
+        _sink = None
+        return None
+    _sink = np.zeros(int(p), dtype=np.int32)
+    lib().oracle_set_sweep_sink(_sink.ctypes.data_as(C.c_void_p))
+    return _sink
 
 
 def set_cd_form(form=0):

@@ -59,6 +59,11 @@
  *   iterates in exact arithmetic, K^2 instead of 4 K m flops per sweep.  Never the parity oracle. */
 static int g_col_chunk = 100;
 static int g_cd_form = 0;
+/* g_sweep_sink: test diagnostic — when set (p ints), every column step writes each gene's sweep count of its solve there
+ *   (the last column step of a call wins): lets a test find the gene and outer iteration at which two implementations'
+ *   stopping decisions (src/coordinate_descent.cpp:114) first differ. */
+static int *g_sweep_sink = 0;
+void oracle_set_sweep_sink(int *sink) { g_sweep_sink = sink; }
 void oracle_set_col_chunk(int chunk) { g_col_chunk = chunk < 1 ? 1 : chunk; }
 void oracle_set_cd_form(int form) { g_cd_form = form ? 1 : 0; }
 
@@ -599,6 +604,7 @@ int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x
                     oracle_strong_cd(feat, outc, m, K, cj, lambda, alpha, XtX, Xty, tol, seed,
                                      (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
                 sweeps_sum += sw;
+                if (g_sweep_sink) g_sweep_sink[j] = sw;
                 for (int a = 0; a < K; a++) cj[a] = beta[a];
             }
             free(feat); free(outc); free(XtX); free(Xty); free(beta);
@@ -642,6 +648,7 @@ int oracle_optimize_col(const double *X, const uint8_t *M, const double *R /*n x
                     oracle_strong_cd(R, xcol, n, K, cj, lambda, alpha, gram, Xty, tol, seed,
                                      (uint32_t)(gene_offset + j), iter, order_mode, max_sweeps, beta, &sw);
                 sweeps_sum += sw;
+                if (g_sweep_sink) g_sweep_sink[j] = sw;
                 for (int a = 0; a < K; a++) cj[a] = beta[a];
             }
             free(Xty); free(beta);

@@ -785,3 +785,41 @@ def test_operators_reject_bad_arguments():
     with pytest.raises(_lib.InsiderError):
         ds.optimize_col(A, C, tuning=2)
     ds.close()
+
+
+@pytest.mark.parametrize("K", [7, 30])
+def test_device_order_table_matches_golden(K):
+    """The sweep-order table the device kernels read (k_order_table) against the committed golden orders of
+    include/insider_perm.h (tests/golden/perm_golden.json): oracle and product share that header, so only fixed bytes can
+    catch an edit of it.  Also decodes the successor list the register-resident sweep kernel jumps through."""
+    import ctypes as C
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "perm_golden.json")))
+    w = workloads.small(K=K, n=60, p=20, seed=3)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    checked = 0
+    for seed, it in sorted({(g["seed"], g["iter"]) for g in gold}):
+        A, Cm = _cp(w)
+        ds.optimize_col(A, Cm, lambda_=w.lam, alpha=0.4, tuning=1, tol=1e-3, seed=seed, it=it)
+        rows = 16384 + 1
+        tab = np.zeros(rows * 320, dtype=np.uint8)
+        _lib.check(_lib.load().insider_hip_get_array(ds._h, b"order_table", tab.ctypes.data_as(C.c_void_p), tab.nbytes))
+        tab = tab.reshape(rows, 320)
+        for g in gold:
+            if (g["seed"], g["iter"], g["K"]) != (seed, it, K):
+                continue
+            row = tab[g["sweep"] % 16384]
+            assert row[:K].tolist() == g["order"], g
+            # successor list (bytes 128..): dword 0 = first block, dword 1 + k = block after coordinate k, exit block last
+            blk = row[128:128 + 4 * 48].view(np.uint32)
+            unit = 96                                   # INSIDER_REG_BLOCK: bytes between the code blocks of two coordinates
+            walk, cur = [], int(blk[0]) // unit
+            while len(walk) < K:
+                walk.append(cur)
+                cur = int(blk[1 + cur]) // unit
+            assert walk == g["order"], (walk, g)
+            checked += 1
+        assert np.array_equal(tab[16384], tab[0])      # the look-ahead row = sweep 16384 = sweep 0 of the next period
+    ds.close()
+    assert checked == 72

@@ -163,3 +163,16 @@ def test_covariance_form_variant_matches_reference_form(oracle):
     assert np.array_equal(r1["column_factor"], ref["column_factor"]) and r1["total_sweeps"] == ref["total_sweeps"]
     assert np.max(np.abs(r2["column_factor"] - ref["column_factor"])) < 1e-8
     assert abs(r2["total_sweeps"] - ref["total_sweeps"]) <= 0.01 * ref["total_sweeps"] + 2
+
+
+def test_sweep_order_golden_bytes(oracle):
+    """The sweep-order spec is SHARED by the oracle and the HIP kernels (include/insider_perm.h), so the parity tests cannot
+    see an edit of it: these committed vectors (tests/golden/perm_golden.json, made by tests/golden/make_perm_golden.py) do.
+    Both restatements — the compiled oracle and the numpy one — must reproduce every one of them."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "perm_golden.json")))
+    assert len(gold) == 288
+    for g in gold:
+        assert oracle.sweep_order(g["K"], g["seed"], g["iter"], g["sweep"]) == g["order"], g
+        assert NO.sweep_order(range(g["K"]), g["seed"], 0, g["iter"], g["sweep"], 0) == g["order"], g
+        assert sorted(g["order"]) == list(range(g["K"]))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # VGPR / SGPR / scratch use of the kernels matching $1 (default: the register-resident sweep kernels) in the shipped library
 R=$(dirname $(dirname $(readlink -f $0)))
-T=$(mktemp -d); cp $R/insider_amd/libinsider_hip.so $T/lib.so; cd $T
+T=$(mktemp -d); cp ${LIB:-$R/insider_amd/libinsider_hip.so} $T/lib.so; cd $T
 /opt/rocm/lib/llvm/bin/llvm-objdump --offloading lib.so > /dev/null
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes lib.so.0.hipv4-amdgcn-amd-amdhsa--gfx950 | python3 -c "
 import sys,re

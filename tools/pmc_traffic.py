@@ -18,12 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def source_sha():
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "insider_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    from insider_amd import _build
+    return _build.source_sha()
 
 
 def series(d, counter):
