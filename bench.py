@@ -52,6 +52,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the baseline sample")
     ap.add_argument("--grid", action="store_true", help="also time tune()'s lambda x alpha grid on the resident data set (N = 1)")
+    ap.add_argument("--concurrent", type=int, default=1, help="--grid: also time the grid with this many grid points fitted at the same "
+                    "time on the one GPU (handles of the shared resident data set, insider_hip_clone)")
+    ap.add_argument("--ctns", type=int, default=0, metavar="M", help="add M continuous covariates (N(0, 1) columns of ctns_confounder, "
+                    "optimize_continuous_v2, src/optimize.cpp:76-137) to the workload")
+    ap.add_argument("--latent", type=int, default=0, metavar="K", help="override the workload's latent dimension (K range study: "
+                    "K <= 32 register-resident sweeps, 33..63 one gene per wavefront, > 63 unsupported)")
     ap.add_argument("--seed", type=int, default=20240301)
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="library option (insider_hip_set_option), repeatable")
     return ap.parse_args()
@@ -161,7 +167,7 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
                      "ratio can be separated from the hardware part")}
 
 
-def grid_bench(ds, w, K, steps, warm_start=False):
+def grid_bench(ds, w, K, steps, warm_start=False, concurrent=1, rank=0, world=1):
     """BASELINE config 3 as written: tune()'s lambda x alpha grid (README.md:79 of the reference: lambda in {1,3,..,19},
     alpha in {0.2,..,0.5}) on the resident data set, tuning_iter = steps - 1, fresh inits per point (R/insider.R:142-174)."""
     from insider_amd import api
@@ -180,13 +186,16 @@ def grid_bench(ds, w, K, steps, warm_start=False):
     import io
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
-        res = api.tune(obj, latent_dimension=np.array([K]), lambda_=lambdas, alpha=alphas, timings=timings, warm_start=warm_start)
+        res = api.tune(obj, latent_dimension=np.array([K]), lambda_=lambdas, alpha=alphas, timings=timings, warm_start=warm_start,
+                       concurrent=concurrent, rank=rank, world=world)
     wall = time.perf_counter() - t0
+    clones = obj.get("_tune_clones", [])
     tab = res["reg_tuning"]
     best = tab[int(np.argmin(tab[:, 3]))]
     npts = len(timings)
     return {"points": npts, "lambda": lambdas, "alpha": alphas, "iterations_per_point": steps, "wall_s": wall,
-            "warm_start": bool(warm_start), "table": [[float(v) for v in row] for row in tab],
+            "warm_start": bool(warm_start), "concurrent": int(concurrent), "table": [[float(v) for v in row] for row in tab],
+            "_clones": clones,
             "mean_outer_iterations_per_s": npts * steps / wall,
             "per_point_ms": {"init_draw": 1e3 * float(np.mean([t["init_s"] for t in timings])),
                              "init_draw_not_hidden": 1e3 * float(np.mean([t["init_wait_s"] for t in timings])),
@@ -199,6 +208,42 @@ def grid_bench(ds, w, K, steps, warm_start=False):
             "note": ("host_overhead = what the per-point wall time exceeds the time inside the library by: 2 x factor transfer over PCIe, "
                      "Python, and the part of the init draw (numpy, 1.5 M normals, on a helper thread during the previous point's fit) "
                      "that was not hidden; X / masks / lists stay resident")}
+
+
+def grid_parallel_bench(args, rank, world, local_rank, one_gpu):
+    """BASELINE config 3's tune() grid dealt over the ranks (SURVEY.md 8f N1, R/insider.R:142-174): every rank keeps the WHOLE
+    c3 data set resident on its GPU and fits the grid points g % world == rank (api.tune(rank, world)); the result tables are
+    summed over torch.distributed (RCCL; gloo in the one-GPU rehearsal).  The split of config 3 that has no latency floor:
+    the fits are independent, nothing is exchanged inside them."""
+    import torch
+    import torch.distributed as dist
+    from insider_amd import api, workloads
+    n, p, _, _, K, lam, alpha, tuning, f = workloads.CONFIGS["c3"]
+    t0 = time.perf_counter()
+    w = workloads.make("c3")
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, device=local_rank)
+    ds.set_option("profile", 1)
+    t_setup = time.perf_counter() - t0
+    dist.barrier()
+    torch.cuda.synchronize()
+    g = grid_bench(ds, w, K, args.steps, concurrent=args.concurrent, rank=rank, world=world)
+    torch.cuda.synchronize()
+    t = torch.tensor([g["wall_s"]], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    for hd in g.pop("_clones"):
+        hd.close()
+    ds.close()
+    wall = float(t.item())
+    tab = np.array(g.pop("table"))
+    best = tab[int(np.argmin(tab[:, 3]))]
+    return {"workload": f"c3: {n}x{p} fp64, K={K}, 10% held out, the whole data set resident on every GPU", "points": len(tab),
+            "points_per_rank": g["points"], "lambda": g["lambda"], "alpha": g["alpha"], "iterations_per_point": args.steps,
+            "concurrent_per_gpu": int(args.concurrent), "wall_s_max_over_ranks": wall,
+            "mean_outer_iterations_per_s": len(tab) * args.steps / wall,
+            "grid_points_per_s": len(tab) / wall, "setup_s_rank0": t_setup,
+            "table_complete": bool(np.all(tab[:, 2] > 0)), "table": [[float(v) for v in row] for row in tab], "best": {"lambda": float(best[0]), "alpha": float(best[1]), "test_rmse": float(best[3])},
+            "exchange": "one sum-all-reduce of the 40 x 4 result table after the grid (torch.distributed, " + dist.get_backend() + ")",
+            "note": "fresh inits of ALL grid points are drawn on every rank in the reference's order: the table does not depend on the rank count"}
 
 
 def self_launch(n_gpus):
@@ -252,15 +297,20 @@ def main():
     name = args.workload or ("c3" if world == 1 else "c4")
     scaling = args.scaling or "strong"
     n, p_total, _, _, K, lam, alpha, tuning, f = workloads.CONFIGS[name]
+    if args.latent > 0:
+        K = args.latent
     weak = scaling == "weak" and world > 1
     slabs = world if weak else 1          # weak scaling: the problem grows with the GPU count
     p_total *= slabs
     lo, hi = idist.shard_range(p_total, rank, world)
     t0 = time.perf_counter()
-    w = workloads.make(name, p=p_total, gene_range=(lo, hi))
+    w = workloads.make(name, p=p_total, gene_range=(lo, hi), K=K if args.latent > 0 else None)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, device=local_rank)
+    Z = None
+    if args.ctns > 0:      # continuous covariates: the same N(0, 1) columns on every rank
+        Z = np.asfortranarray(np.random.Generator(np.random.PCG64([workloads.DATA_SEED, 7])).standard_normal((n, args.ctns)))
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, device=local_rank, ctns_confounder=Z)
     t_up = time.perf_counter() - t0
     if world > 1 and not one_gpu:
         # in-library RCCL (ncclAllReduce on the library's stream); if any rank cannot join, all ranks fall back together
@@ -287,11 +337,14 @@ def main():
     def inits(seed):
         """N(0, 1e-6) inits (R/utils.R:40-43): optimize() updates its factor arguments in place (like the reference)."""
         A0, C0 = workloads.init_factors(w.n_levels, K, p_total, seed)
+        if args.ctns > 0:
+            A0 = A0 + [np.asfortranarray(np.random.Generator(np.random.PCG64([seed, 9])).normal(0.0, 0.001, size=(args.ctns, K)))]
         return A0, np.asfortranarray(C0[:, lo:hi])
 
     def run(iters, seed, start, lam_):
         A, C = start
-        return ds.optimize(A, C, K, lam_, lam_, alpha, tuning=tuning, max_iter=iters - 1, global_tol=-1.0, seed=seed)
+        return ds.optimize(A, C, K, lam_, lam_, alpha, tuning=tuning, max_iter=iters - 1, global_tol=-1.0, seed=seed,
+                           inc_continuous=1 if args.ctns > 0 else 0)
 
     def sync():
         if world > 1:
@@ -332,6 +385,12 @@ def main():
         except Exception:
             return None
 
+    gp = None
+    if world > 1 and args.grid:      # the grid-parallel split of config 3, next to the (unchanged) strong-scaling figure above
+        try:
+            gp = grid_parallel_bench(args, rank, world, local_rank, one_gpu)
+        except Exception as e:
+            gp = {"failed": repr(e)}
     if rank == 0:
         gram_ms = prof["col_stats_ms"] / max(prof["col_stats_launches"], 1)
         cd_ms = prof["cd_ms"] / max(prof["cd_launches"], 1)
@@ -395,7 +454,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}: {n}x{p_total} fp64, K={K}, lambda={lam}, alpha={alpha}, "
-                                   f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}",
+                                   f"{int(f * 100)}% held out, tuning={tuning}, levels={list(map(int, w.n_levels))}"
+                                   + (f", {args.ctns} continuous covariates" if args.ctns > 0 else ""),
                        "genes_per_gpu": p_loc, "problem_iterations_per_s": args.steps / dt,
                        "value_is": (f"{slabs} x outer iterations/s of the {n}x{p_total} problem (one {name}-sized gene slab per GPU)"
                                     if slabs > 1 else f"outer iterations/s of the {n}x{p_total} problem"),
@@ -439,7 +499,8 @@ def main():
                 "row_update": "merged (per (level, gene) pair)" if prof.get("row_merged") else "per-sample statistics (k_list_stats)",
                 "note": ("achieved = executed v_mfma_f64_16x16x4 flops (2048 each) / time against the 78.6 TF f64 matrix peak; the "
                          "per-entry list form of the same statistics (option col_factored = 0) is the streaming-equivalent kernel")},
-            "cd_kernel": {"kernel": "k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)",
+            "cd_kernel": {"kernel": ("k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)"
+                                     if K <= 32 else "k_cd_cols<64, 1> (K > 32: one gene per wavefront, Gram matrix in LDS, v_readlane broadcasts)"),
                           "avg_launch_ms": cd_ms, "traffic": tr_cd,
                           "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,
                           "coordinate_updates_per_s": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9),
@@ -474,15 +535,27 @@ def main():
         if args.grid and world == 1:
             try:
                 out["grid"] = grid_bench(ds, w, K, args.steps)
+                out["grid"].pop("_clones")
+                if args.concurrent > 1:
+                    # k grid points at a time, each on its own handle of the shared resident data set (same tables, bit for bit)
+                    gc_ = grid_bench(ds, w, K, args.steps, concurrent=args.concurrent)
+                    for hd in gc_.pop("_clones"):
+                        hd.close()
+                    gc_["identical_to_serial_grid"] = bool(np.array_equal(np.array(gc_.pop("table")), np.array(out["grid"]["table"])))
+                    gc_["speedup_vs_serial_grid"] = out["grid"]["wall_s"] / gc_["wall_s"]
+                    out["grid_concurrent"] = gc_
                 # opt-in extension (NOT the reference's behaviour): every grid point starts from its nearest finished neighbour
                 gw = grid_bench(ds, w, K, args.steps, warm_start=True)
-                cold = np.array(out["grid"].pop("table"))
+                gw.pop("_clones")
+                cold = np.array(out["grid"]["table"])
                 warm = np.array(gw.pop("table"))
                 gw["max_abs_test_rmse_difference_vs_cold"] = float(np.max(np.abs(cold[:, 3] - warm[:, 3])))
                 gw["best_point_agrees_with_cold"] = bool(np.argmin(cold[:, 3]) == np.argmin(warm[:, 3]))
                 out["grid_warm_start"] = gw
             except Exception as e:
                 out["grid"] = {"failed": repr(e)}
+        if world > 1 and args.grid:
+            out["grid_parallel"] = gp
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is an N = 1 figure
             try:
                 out["cpu_baseline"] = cpu_baseline(name, lam, alpha, host_cores(),

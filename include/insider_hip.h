@@ -85,6 +85,15 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
                           insider_hip_handle **out);
 void insider_hip_destroy(insider_hip_handle *h);
 
+/* A second handle on the SAME resident data set: the read-only device arrays insider_hip_create built (X, mask codes,
+ * held-out lists, level sums, pair counts: all of it) are shared, the factor workspace, the streams and the options (copied
+ * from `src` as they stand) are the clone's own.  Handles of one data set may run insider_hip_optimize() at the same time
+ * from different host threads: tune()'s grid points (R/insider.R:142-174) are independent fits of one data set, and a
+ * data set of the size real INSIDER inputs have (377 x 5000 ... 44477, README.md:30) does not fill the GPU with one fit.
+ * Every handle is destroyed with insider_hip_destroy(); the data set is freed with the last of them.  Results of a fit do
+ * not depend on which handle ran it or on what ran beside it. */
+int insider_hip_clone(insider_hip_handle *src, insider_hip_handle **out);
+
 /* Gene-axis sharding: this handle holds genes [gene_offset, gene_offset + p) of the global
  * matrix.  gene_offset keys the per-gene sweep order so results do not depend on the sharding.  `fn` (may be
  * NULL when world == 1, or when insider_hip_comm_init() supplies the exchange) is called once per covariate per outer

@@ -25,7 +25,7 @@ SYMBOLS = (
     "insider_hip_optimize_oneshot", "insider_hip_optimize_row", "insider_hip_optimize_col", "insider_hip_strong_cd", "insider_hip_masked_gram_cols",
     "insider_hip_masked_gram_rows", "insider_hip_get_profile", "insider_hip_get_sweeps", "insider_hip_last_cd_ms",
     "insider_hip_optimize_oneshot_ex", "insider_hip_strong_cd_xy", "insider_hip_solve_sympd", "insider_hip_get_info",
-    "insider_hip_comm_unique_id", "insider_hip_comm_init", "insider_hip_get_array",
+    "insider_hip_comm_unique_id", "insider_hip_comm_init", "insider_hip_get_array", "insider_hip_clone",
 )
 COMM_ID_BYTES = 128
 
@@ -67,6 +67,7 @@ def load():
                                        C.POINTER(C.c_void_p)]
     lib.insider_hip_create_ex.argtypes = [dp, C.c_int64, C.c_int64, i32p, C.c_int, i32p, dp, C.c_int, u8p, u8p, C.c_int,
                                           C.POINTER(C.c_void_p)]
+    lib.insider_hip_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.insider_hip_destroy.argtypes = [C.c_void_p]
     lib.insider_hip_destroy.restype = None
     lib.insider_hip_set_shard.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]

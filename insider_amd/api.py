@@ -54,6 +54,17 @@ class InsiderData:
                                              _lib.ptr(Mte, C.c_uint8), int(device), C.byref(self._h)))
         self._cb = None  # keeps the ctypes callback alive
 
+    def clone(self):
+        """Another handle on the SAME resident data set (insider_hip_clone): the device copy of X, the lists and the
+        count tables are shared, the factor workspace, streams and options (copied as they stand) are its own.  Handles of
+        one data set may fit at the same time from different threads (tune(concurrent=k))."""
+        other = object.__new__(InsiderData)
+        other.n, other.p, other.c, other.m, other.n_levels = self.n, self.p, self.c, self.m, self.n_levels
+        other._h = C.c_void_p()
+        other._cb = None
+        _lib.check(_lib.load().insider_hip_clone(self._h, C.byref(other._h)))
+        return other
+
     def set_option(self, name, value):
         _lib.check(_lib.load().insider_hip_set_option(self._h, name.encode(), float(value)))
 
@@ -452,8 +463,17 @@ def _nearest_finished(done, g, n_lambda):
     return best
 
 
+def _tune_handles(obj, ds, k):
+    """k handles on the resident tune() data set: the data set's own plus k - 1 clones (insider_hip_clone: shared device
+    arrays, private workspaces), kept on the object for the next call."""
+    clones = obj.setdefault("_tune_clones", [])
+    while len(clones) < k - 1:
+        clones.append(ds.clone())
+    return [ds] + clones[: k - 1]
+
+
 def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=None, rank=0, world=1, timings=None,
-         warm_start=False):
+         warm_start=False, concurrent=1):
     """tune() of R/insider.R:81-176.  ``out_dir``: where to write the reference's CSVs (None = do not write).
 
     ``warm_start`` (opt-in, NOT the reference's behaviour, which draws fresh N(0, 0.001^2) inits for every grid point,
@@ -466,7 +486,17 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
     whole data set resident, grid point g is fitted by rank g % world and the result tables are summed over
     torch.distributed.  The fresh inits of ALL grid points are drawn on every rank, in the reference's order, so
     the tables do not depend on ``world``.  ``timings``: a list that receives one dict per fitted point
-    (init_s = drawing the fresh inits, optimize_s = the optimize() call, library_ms = time inside the library)."""
+    (init_s = drawing the fresh inits, optimize_s = the optimize() call, library_ms = time inside the library).
+
+    ``concurrent`` = k > 1: k grid points of this rank are fitted AT THE SAME TIME on the one GPU, each on its own handle of
+    the shared resident data set (InsiderData.clone) from its own host thread.  The grid points are independent fits
+    (R/insider.R:145-164), and a data set of the size real INSIDER inputs have does not fill an MI355X with one fit: its
+    column step is bound by its longest gene's sequential sweep chain, which a second fit overlaps.  The inits are still
+    drawn by ONE generator in the reference's order, and every point's result is bit-identical to the serial grid's
+    (tests/test_gpu_parity.py::test_concurrent_tune_is_bit_identical).  Not combinable with ``warm_start`` (whose
+    starting points depend on the order in which fits finish)."""
+    if concurrent > 1 and warm_start:
+        raise ValueError("tune(): concurrent > 1 and warm_start exclude each other")
     import time as _time
     lat = np.atleast_1d(latent_dimension) if latent_dimension is not None else np.array([])
     lam = np.atleast_1d(np.asarray(lambda_, dtype=float))
@@ -517,10 +547,59 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
             v = _fresh_inits(obj, latent_rank, rng)
             return v, _time.perf_counter() - t_0
 
+        if concurrent > 1:
+            import queue
+            import threading
+            handles = _tune_handles(obj, ds, int(concurrent))
+            ready = queue.Queue(maxsize=2 * len(handles))      # inits drawn ahead of the fits, in the reference's order
+            lock = threading.Lock()
+            errors = []
+
+            def _producer():
+                for g in range(len(grid)):
+                    v, t_draw = _draw()
+                    if g % world == rank:
+                        ready.put((g, v, t_draw))
+                for _ in handles:
+                    ready.put(None)
+
+            def _worker(hd):
+                while True:
+                    item = ready.get()
+                    if item is None or errors:
+                        if item is not None:
+                            continue        # drain after a failure elsewhere
+                        return
+                    g, (cfd, col), t_draw = item
+                    l_r, a_r = grid[g]
+                    t_1 = _time.perf_counter()
+                    try:
+                        fitted = hd.optimize(cfd, col, latent_rank, l_r, l_r, a_r, 1, prm["global_tol"], prm["sub_tol"],
+                                             prm["tuning_iter"], seed=obj.get("seed", DEFAULT_SEED),
+                                             inc_continuous=obj["inc_continuous"])
+                    except Exception as e:      # reported by the caller's thread
+                        errors.append(e)
+                        continue
+                    with lock:
+                        print(f"parameter grid: {l_r},{a_r} ---------------------------------")
+                        rows[g] = (l_r, a_r, fitted["train_rmse"], fitted["test_rmse"])
+                        if timings is not None:
+                            timings.append(dict(lambda_=l_r, alpha=a_r, init_s=t_draw, init_wait_s=0.0, warm_from=None,
+                                                optimize_s=_time.perf_counter() - t_1, library_ms=hd.profile()["wall_ms"]))
+
+            threads = [threading.Thread(target=_producer)] + [threading.Thread(target=_worker, args=(hd,)) for hd in handles]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            if csv and world == 1:
+                np.savetxt(csv, rows, delimiter=",")
         finished = {}       # warm_start: grid index -> (row factors, column factor) of the points this rank has fitted
         with ThreadPoolExecutor(max_workers=1) as pool:
-            nxt = pool.submit(_draw)
-            for g, (l_r, a_r) in enumerate(grid):                                                        # :147-150
+            nxt = pool.submit(_draw) if concurrent <= 1 else None
+            for g, (l_r, a_r) in enumerate(grid if concurrent <= 1 else []):                             # :147-150
                 t_w = _time.perf_counter()
                 (cfd, col), t_draw = nxt.result()
                 t_wait = _time.perf_counter() - t_w

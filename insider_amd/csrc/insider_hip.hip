@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,11 @@ struct CovTables {   // per covariate, device
 
 struct insider_hip_handle {
     int device = 0;
+    // The read-only DATA SET (X-derived lists, level sums, pair counts, chunk tables: everything insider_hip_create builds)
+    // may be shared by several handles (insider_hip_clone): each has its own factor workspace, streams and options, so that
+    // several fits of one data set — tune()'s grid points — run on the GPU at the same time.  The device arrays are freed
+    // by the last handle that goes.
+    std::atomic<int> *data_refs = nullptr;
     hipStream_t stream = nullptr;
     // scheduling work that nothing but the next column solve needs (sweep keys -> gene order, the next iteration's sweep-order
     // table) runs on a side stream, next to the row update, between two events
@@ -223,44 +229,39 @@ namespace {
 
 constexpr int MM_SLAB = 128;  // rows per partial of the reduction products (insider_mm.hpp)
 
-void free_workspace(insider_hip_handle *h)
+// every K-dependent device buffer of a handle (ensure_workspace), as pointer slots
+std::vector<void **> workspace_slots(insider_hip_handle *h)
 {
-    double **ptrs[] = {&h->Astack, &h->R, &h->C, &h->RtR, &h->CCt, &h->Qfull, &h->SC, &h->stat, &h->stat_col, &h->gram_part,
-                       &h->sc_part, &h->gram_part2, &h->sc_part2, &h->lvl_part, &h->lvl_sum, &h->lvl_sum_all, &h->U, &h->Ylvl, &h->wpart, &h->Vlev, &h->Qheld, &h->eq, &h->sse_train, &h->sse_test, &h->b2, &h->b1, &h->loss_buf,
-                       &h->stage};
-    for (auto pp : ptrs) { if (*pp) (void)hipFree(*pp); *pp = nullptr; }
-    if (h->wg_part) (void)hipFree(h->wg_part);
-    if (h->wg_pair) (void)hipFree(h->wg_pair);
-    h->wg_part = nullptr;
-    h->wg_pair = nullptr;
-    if (h->sweeps) (void)hipFree(h->sweeps);
-    if (h->sweep_key) (void)hipFree(h->sweep_key);
-    h->sweep_key = nullptr;
-    if (h->failflag) (void)hipFree(h->failflag);
-    if (h->sweep_total) (void)hipFree(h->sweep_total);
-    for (auto &b : h->order_buf) { if (b) (void)hipFree(b); b = nullptr; }
+    std::vector<void **> v;
+    auto add = [&v](auto &ptr) { v.push_back(reinterpret_cast<void **>(&ptr)); };
+    add(h->Astack); add(h->R); add(h->C); add(h->RtR); add(h->CCt); add(h->Qfull); add(h->SC); add(h->stat); add(h->stat_col);
+    add(h->gram_part); add(h->sc_part); add(h->gram_part2); add(h->sc_part2); add(h->lvl_part); add(h->lvl_sum); add(h->lvl_sum_all);
+    add(h->U); add(h->Ylvl); add(h->wpart); add(h->Vlev); add(h->Qheld); add(h->eq); add(h->sse_train); add(h->sse_test); add(h->b2);
+    add(h->b1); add(h->loss_buf); add(h->stage); add(h->wg_part); add(h->wg_pair); add(h->sweeps); add(h->sweep_key); add(h->failflag);
+    add(h->sweep_total); add(h->order_buf[0]); add(h->order_buf[1]); add(h->gene_perm); add(h->sched_cnt[0]); add(h->sched_cnt[1]);
+    add(h->sched_rank); add(h->sched_bkt); add(h->sched_long); add(h->cd_hsave); add(h->cd_isave); add(h->cd_pass_slot);
+    add(h->cd_pass_perm[0]); add(h->cd_pass_perm[1]); add(h->cd_pass_cnt);
+    for (int e = 0; e < insider_hip_handle::EARLY; ++e) add(h->perm_early[e]);
+    return v;
+}
+
+// drop the workspace WITHOUT freeing it (a clone starts from a copy of its source's fields: the buffers are the source's)
+void forget_workspace(insider_hip_handle *h)
+{
+    for (void **slot : workspace_slots(h)) *slot = nullptr;
     h->order = nullptr;
     h->order_rows = 0;
-    for (void *q : {(void *)h->gene_perm, (void *)h->sched_cnt[0], (void *)h->sched_cnt[1], (void *)h->sched_rank, (void *)h->sched_bkt, (void *)h->sched_long, (void *)h->cd_hsave,
-                    (void *)h->cd_isave, (void *)h->cd_pass_slot, (void *)h->cd_pass_perm[0], (void *)h->cd_pass_perm[1],
-                    (void *)h->cd_pass_cnt})
-        if (q) (void)hipFree(q);
-    h->gene_perm = h->sched_cnt[0] = h->sched_cnt[1] = h->sched_rank = h->sched_long = nullptr;
-    h->sched_bkt = nullptr;
     h->sched_long_valid = false;
-    h->cd_hsave = h->cd_isave = nullptr;
-    h->cd_pass_slot = nullptr;
-    h->cd_pass_perm[0] = h->cd_pass_perm[1] = h->cd_pass_cnt = nullptr;
-    for (int e = 0; e < insider_hip_handle::EARLY; ++e) {
-        if (h->perm_early[e]) (void)hipFree(h->perm_early[e]);
-        h->perm_early[e] = nullptr;
-        h->have_early[e] = false;
-    }
+    for (int e = 0; e < insider_hip_handle::EARLY; ++e) h->have_early[e] = false;
     h->have_perm = false;
-    h->sweep_total = nullptr;
-    h->sweeps = nullptr;
-    h->failflag = nullptr;
     h->K = 0;
+}
+
+void free_workspace(insider_hip_handle *h)
+{
+    for (void **slot : workspace_slots(h))
+        if (*slot) (void)hipFree(*slot);
+    forget_workspace(h);
 }
 
 // The weighted SYRK of covariate i as a GEMM over genes (k_wgemm, insider_row_merged.hpp)?  Needs the static half-count table
@@ -285,7 +286,8 @@ WgPlan wgemm_plan(const insider_hip_handle *h, int i, int K, bool whatever_the_o
     const int waves_per_slab = cdiv(w.ntile, 2) * w.zch;
     // one wave per SIMD: the kernel runs beside the main stream's V -> u -> U'C chain (other waves fill the machine), its
     // operands are prefetched a step ahead, and every slab costs a partial record (levels x pairs doubles) to write and re-read
-    const int want = std::max(1, std::min<int>(cdiv(h->wg_waves, waves_per_slab), (int)cdiv(h->p, 64)));
+    // (rounded DOWN: at most wg_waves waves in all — with the default, one per SIMD: a surplus block would run as a second round)
+    const int want = std::max(1, std::min<int>(h->wg_waves / waves_per_slab, (int)cdiv(h->p, 64)));
     w.slab = (int)round_up(cdiv(h->p, want), 4);
     w.nslab = (int)cdiv(h->p, w.slab);
     w.use = true;
@@ -669,6 +671,9 @@ int launch_col_stats(insider_hip_handle *h, bool timed, bool split = false)
                 h->long_pending = true;
                 a.skip_bkt = h->sched_bkt;
                 a.skip_last = h->sched_long + 1;
+                // the all-gene launch below reads sched_long / sched_bkt too, which k_sched_scatter wrote on the side stream:
+                // the main stream must see them as well (it otherwise waits for the side stream only before the solve)
+                if (h->side_pending) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_side_done, 0));
             }
             rc = launch_paircnt(h, a, cdiv(h->p, 4), h->stream);
             if (rc) return rc;
@@ -870,7 +875,9 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         KCHECK();
     }
     if (solve && alpha != 0.0) {
-        // schedule the next solve longest-first, genes of similar length sharing a wave (stable sort: deterministic)
+        // schedule the next solve longest-first, genes of similar length sharing a wave.  (The bucket sort's order inside a
+        // bucket is the order of the solve kernel's atomics: which genes share a wave — and so the timings — may differ from
+        // run to run; no result depends on it.)
         hipStream_t st = h->stream;
         if (side) {
             HIPCHECK(hipEventRecord(h->ev_cd_done, h->stream));
@@ -991,10 +998,10 @@ int launch_level_gram(insider_hip_handle *h, int i, hipStream_t st, double *rec)
     if (w.use) {
         const int stat_len = h->NB * (h->NB + 1) / 2 * 256, plen = stat_len + 2 * h->KP + 2;
         const float *hn = h->cf_hn + h->cf.hn_off[h->cf_pos[i]];
-        const dim3 grid(cdiv(w.ntile, 8), w.nslab, w.zch);
+        const dim3 grid(cdiv(cdiv(w.ntile, 2) * w.nslab, 4), 1, w.zch);   // (slab, pair-tile pair) items, four waves per block
 #define WG_LAUNCH(LT_)                                                                                                     \
     hipLaunchKernelGGL((k_wgemm<LT_>), grid, dim3(256), 0, st, hn, h->cf.hn_stride, w.tiles, (const double *)h->C, h->KP,   \
-                       (int)h->p, w.slab, (const uint8_t *)h->wg_pair, w.ntile, h->wg_part)
+                       (int)h->p, w.slab, w.nslab, (const uint8_t *)h->wg_pair, w.ntile, h->wg_part)
         switch (w.LT) {
             case 4: WG_LAUNCH(4); break;
             case 5: WG_LAUNCH(5); break;
@@ -1323,14 +1330,46 @@ int insider_hip_device_count(void)
     return n;
 }
 
-void insider_hip_destroy(insider_hip_handle *h)
+namespace {
+// streams and events of one handle (each handle, clones included, has its own)
+hipError_t make_streams(insider_hip_handle *h)
 {
-    if (!h) return;
-    (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
-    clear_events(h);
-    free_workspace(h);
+    hipError_t e;
+#define MS(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
+    MS(hipStreamCreate(&h->stream));
+    MS(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    MS(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    MS(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
+    MS(hipStreamCreateWithFlags(&h->lng, hipStreamNonBlocking));
+    MS(hipEventCreateWithFlags(&h->ev_long_go, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_long_done, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_a_ready, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_qfull, hipEventDisableTiming));
+    h->ev_w.assign(h->c > 0 ? h->c : 1, nullptr);
+    for (auto &ev : h->ev_w) MS(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_tab, hipEventDisableTiming));
+#undef MS
+    return hipSuccess;
+}
+
+void destroy_streams(insider_hip_handle *h)
+{
+    for (hipStream_t *st : {&h->side, &h->side2, &h->side3, &h->lng}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
+    for (hipEvent_t *ev : {&h->ev_long_go, &h->ev_long_done, &h->ev_prep, &h->ev_c_ready, &h->ev_a_ready, &h->ev_qfull, &h->ev_cd_done,
+                           &h->ev_side_done, &h->ev_tab}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
+    for (auto ev : h->ev_w) if (ev) (void)hipEventDestroy(ev);
+    h->ev_w.clear();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = nullptr;
+}
+
+// the device arrays of the data set (everything insider_hip_create_ex builds that does not depend on K or on the factors)
+void free_data_set(insider_hip_handle *h)
+{
     void *ptrs[] = {h->X, h->Xt, h->codes, h->codes_t, h->lev, h->lvl_off_d, h->members_all, h->lvl_ptr_all,
                     h->lvl_count_all, h->S, h->yy_train, h->yy_all, h->col_ptr, h->row_ptr, h->col_idx, h->row_idx,
                     h->col_val, h->row_val, h->col_flag, h->Zc, h->one_count, h->ident_members, h->cont.chunk_begin, h->cont.chunk_end,
@@ -1349,22 +1388,53 @@ void insider_hip_destroy(insider_hip_handle *h)
     if (h->Sheld) (void)hipFree(h->Sheld);
     if (h->cf_cnt) (void)hipFree(h->cf_cnt);
     if (h->cf_hn) (void)hipFree(h->cf_hn);
-    if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->side2) (void)hipStreamDestroy(h->side2);
-    if (h->side3) (void)hipStreamDestroy(h->side3);
-    if (h->lng) (void)hipStreamDestroy(h->lng);
-    if (h->ev_long_go) (void)hipEventDestroy(h->ev_long_go);
-    if (h->ev_long_done) (void)hipEventDestroy(h->ev_long_done);
-    if (h->ev_prep) (void)hipEventDestroy(h->ev_prep);
-    if (h->ev_c_ready) (void)hipEventDestroy(h->ev_c_ready);
-    if (h->ev_a_ready) (void)hipEventDestroy(h->ev_a_ready);
-    if (h->ev_qfull) (void)hipEventDestroy(h->ev_qfull);
-    for (auto e : h->ev_w) (void)hipEventDestroy(e);
-    if (h->ev_cd_done) (void)hipEventDestroy(h->ev_cd_done);
-    if (h->ev_side_done) (void)hipEventDestroy(h->ev_side_done);
-    if (h->ev_tab) (void)hipEventDestroy(h->ev_tab);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+}  // namespace
+
+void insider_hip_destroy(insider_hip_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipStream_t st : {h->side, h->side2, h->side3, h->lng}) if (st) (void)hipStreamSynchronize(st);
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+    clear_events(h);
+    free_workspace(h);
+    // the data set goes with its last user (insider_hip_clone shares it)
+    if (!h->data_refs || h->data_refs->fetch_sub(1) == 1) {
+        free_data_set(h);
+        delete h->data_refs;
+    }
+    destroy_streams(h);
     delete h;
+}
+
+int insider_hip_clone(insider_hip_handle *src, insider_hip_handle **out)
+{
+    if (!out) return fail(INSIDER_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!src || !src->data_refs) return fail(INSIDER_ERR_ARG, "null handle");
+    HIPCHECK(hipSetDevice(src->device));
+    insider_hip_handle *h = new insider_hip_handle(*src);   // every data-set field and option; the rest is reset below
+    forget_workspace(h);                                    // (the copied pointers are the source's buffers)
+    h->stream = h->side = h->side2 = h->side3 = h->lng = nullptr;
+    h->ev_long_go = h->ev_long_done = h->ev_prep = h->ev_c_ready = h->ev_a_ready = h->ev_qfull = nullptr;
+    h->ev_cd_done = h->ev_side_done = h->ev_tab = nullptr;
+    h->ev_w.clear();
+    for (auto *v : {&h->ev_col, &h->ev_row, &h->ev_cd, &h->ev_test}) v->clear();
+    h->side_pending = h->w_ready = h->qfull_pending = h->long_pending = false;
+    h->comm = nullptr;                                      // a sharded clone joins its own communicator (insider_hip_comm_init)
+    for (double &v : h->prof) v = 0.0;
+    h->steady_cd_ms = h->steady_col_ms = 0.0;
+    h->cap_hits = h->max_gene_sweeps = 0;
+    src->data_refs->fetch_add(1);
+    const hipError_t e = make_streams(h);
+    if (e != hipSuccess) {
+        insider_hip_destroy(h);
+        return fail(e == hipErrorOutOfMemory ? INSIDER_ERR_ALLOC : INSIDER_ERR_HIP, std::string("insider_hip_clone: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return INSIDER_OK;
 }
 
 int insider_hip_create(const double *X, int64_t n, int64_t p, const int32_t *levels, int c, const int32_t *n_levels,
@@ -1418,22 +1488,8 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
 #define CR(x) do { rc = (x); if (rc) { insider_hip_destroy(h); return rc; } } while (0)
 #define CH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { insider_hip_destroy(h); \
         return fail(e_ == hipErrorOutOfMemory ? INSIDER_ERR_ALLOC : INSIDER_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
-    CH(hipStreamCreate(&h->stream));
-    CH(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    CH(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-    CH(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
-    CH(hipStreamCreateWithFlags(&h->lng, hipStreamNonBlocking));
-    CH(hipEventCreateWithFlags(&h->ev_long_go, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_long_done, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_a_ready, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_qfull, hipEventDisableTiming));
-    h->ev_w.resize(c > 0 ? c : 1);
-    for (auto &e : h->ev_w) CH(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
-    CH(hipEventCreateWithFlags(&h->ev_tab, hipEventDisableTiming));
+    h->data_refs = new std::atomic<int>(1);
+    CH(make_streams(h));
     // ---- X (gene-major lines of pitch ldn) and mask codes -------------------------------------------------
     CR(dmalloc(&h->X, (size_t)p * h->ldn));
     CR(dmalloc(&h->codes, (size_t)p * h->ldn));
@@ -1963,7 +2019,9 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     h->side_pending = false;
     {
         unsigned long long bins[256];
-        HIPCHECK(hipMemcpy(bins, h->sweep_total, sizeof(bins), hipMemcpyDeviceToHost));
+        // (on the handle's own stream: a null-stream copy would wait for every other handle's work, insider_hip_clone)
+        HIPCHECK(hipMemcpyAsync(bins, h->sweep_total, sizeof(bins), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
         for (unsigned long long v : bins) sweeps_total += v;
     }
     if (out_train_rmse) *out_train_rmse = train_rmse;

@@ -286,15 +286,21 @@ k_wsyrk(const uint32_t *__restrict__ item_begin, const uint32_t *__restrict__ it
 // k_wgemm_sum (fixed order: reproducible), which also doubles them and writes the level records' blocks.
 template <int LT>
 __global__ void __launch_bounds__(256)
-k_wgemm(const float *__restrict__ hn, int hn_stride, int lt_total, const double *__restrict__ C, int KP, int p, int slab,
+k_wgemm(const float *__restrict__ hn, int hn_stride, int lt_total, const double *__restrict__ C, int KP, int p, int slab, int nslab,
         const uint8_t *__restrict__ pair_ab /*[2][16 ntile]*/, int ntile, double *__restrict__ part /*[slabs][16 lt_total][16 ntile]*/)
 {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int T0 = (blockIdx.x * 4 + w) * 2;            // this wave's pair tiles T0, T0 + 1
-    if (T0 >= ntile) return;
+    // work items = (gene slab, pair of pair tiles), dealt to the waves of the grid densely (round 4: the grid used to carry a
+    // mostly empty fourth block per slab — 276 blocks for 256 CUs, i.e. a second round of 20 blocks that doubled the kernel's
+    // time; now nslab x ceil(ntile / 2) waves, sized by the host to at most one wave per SIMD)
+    const int per = (ntile + 1) >> 1;
+    const int W = blockIdx.x * 4 + w;
+    if (W >= per * nslab) return;
+    const int slab_id = W / per;
+    const int T0 = (W - slab_id * per) * 2;              // this wave's pair tiles T0, T0 + 1
     const int lt0 = blockIdx.z * LT;                     // its level tiles lt0 .. lt0 + LT - 1 (beyond lt_total: skipped at the end)
     const int g4 = lane >> 4, c16 = lane & 15;
-    const int j_begin = blockIdx.y * slab, j_end = j_begin + slab < p ? j_begin + slab : p;
+    const int j_begin = slab_id * slab, j_end = j_begin + slab < p ? j_begin + slab : p;
     // lane offsets in BYTES, fixed for the whole kernel: every load is a wave-uniform base + one of these (+ a constant)
     unsigned off_a[2], off_b[2];
 #pragma unroll
@@ -349,7 +355,7 @@ k_wgemm(const float *__restrict__ hn, int hn_stride, int lt_total, const double 
             }
         }
     }
-    double *out = part + (size_t)blockIdx.y * (16 * lt_total) * (16 * ntile);
+    double *out = part + (size_t)slab_id * (16 * lt_total) * (16 * ntile);
 #pragma unroll
     for (int l = 0; l < LT; ++l)
         if (lt0 + l < lt_total) {   // wave-uniform

@@ -19,21 +19,28 @@ insider_hip_available <- function() {
 # across calls — the shim caches the library handle on the identity of (data, cfd_indicators, train_indicator,
 # test_indicator, ctns_confounder), so the reference's UNMODIFIED tune() loop (R/insider.R:142-174), which calls optimize()
 # once per grid point with the same objects, uploads X once.  insider_hip_cache_clear() frees the cached data sets.
+# HBM retention: the cache holds up to 4 data sets (device copy of X + lists, and it keeps the R objects it is keyed on
+# alive) until they are evicted or cleared.  The reference's fit() (R/insider.R:207-209) builds train + test as a fresh
+# temporary on every call, which can never hit the cache: the default is therefore resident = (tuning == 1) — tune()'s calls
+# stay resident, fit()'s default partition = 0 goes through the one-shot entry (upload, fit, free).
 # The CPU reference is used when no MI355X is visible or the problem is outside the library's limits (K > 63, n or
 # p >= 2^23): the .Call then returns NULL (with a warning) instead of raising an error.
 optimize <- function(data, cfd_factors, column_factor, cfd_indicators, ctns_confounder, train_indicator,
                      test_indicator, inc_continuous, latent_dim, lambda1 = 1.0, lambda2 = 1.0, alpha = 0.1,
                      tuning = 1L, global_tol = 1e-10, sub_tol = 1e-5, max_iter = 10000L,
-                     seed = sample.int(.Machine$integer.max, 1), device = 0L, resident = TRUE) {
+                     seed = sample.int(.Machine$integer.max, 1), device = 0L, resident = (tuning == 1L)) {
     res <- NULL
     if (insider_hip_available())
         res <- .Call("insider_hip_optimize_R", data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
                      train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
                      global_tol, sub_tol, max_iter, seed, device, as.integer(resident))
-    if (is.null(res))
+    if (is.null(res)) {
+        # never silent: the shim has already raised a warning with the reason (no device / K > 63 / n or p >= 2^23)
+        message("insider_hip: optimize() runs on the CPU reference (_insider_optimize) for this call; latent_dim = ", latent_dim)
         res <- .Call(`_insider_optimize`, data, cfd_factors, column_factor, cfd_indicators, ctns_confounder,
                      train_indicator, test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning,
                      global_tol, sub_tol, max_iter)
+    }
     res
 }
 

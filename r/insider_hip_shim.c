@@ -31,6 +31,7 @@
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -207,6 +208,7 @@ static struct {
     const void *data, *lev, *train, *test, *ctns;
     int64_t n, p;
     int c, inc, device;
+    int *n_levels;            /* rows of each cfd_factors element when the handle was created (c entries, malloc'd) */
     SEXP ptr;                 /* preserved external pointer, or NULL */
     unsigned long stamp;
 } g_cache[CACHE_SLOTS];
@@ -219,6 +221,8 @@ SEXP insider_hip_cache_clear_R(void)
             handle_finalizer(g_cache[s].ptr);
             R_ReleaseObject(g_cache[s].ptr);
             g_cache[s].ptr = NULL;
+            free(g_cache[s].n_levels);
+            g_cache[s].n_levels = NULL;
         }
     return R_NilValue;
 }
@@ -250,6 +254,14 @@ static SEXP cached_handle(SEXP data, SEXP cfd_factors, SEXP cfd_indicators, SEXP
         if (g_cache[s].ptr && g_cache[s].data == kd && g_cache[s].lev == kl && g_cache[s].train == ktr && g_cache[s].test == kte &&
             g_cache[s].ctns == kc && g_cache[s].n == n && g_cache[s].p == p && g_cache[s].c == c && g_cache[s].inc == inc &&
             g_cache[s].device == dev && R_ExternalPtrAddr(g_cache[s].ptr)) {
+            /* the key is the identity of the data objects: the factor shapes of THIS call must still be the ones the handle
+             * was built for (its level counts come from them), or upload_factors would read past the caller's matrices */
+            if (TYPEOF(cfd_factors) != VECSXP || Rf_length(cfd_factors) < c) Rf_error("insider_hip: cfd_factors must be a list of %d matrices", c);
+            for (int i = 0; i < c; i++)
+                if (Rf_nrows(VECTOR_ELT(cfd_factors, i)) != g_cache[s].n_levels[i])
+                    Rf_error("insider_hip: cfd_factors[[%d]] has %d rows, the resident data set was created with %d levels for that "
+                             "covariate (insider_hip_cache_clear() drops it)", i + 1, Rf_nrows(VECTOR_ELT(cfd_factors, i)),
+                             g_cache[s].n_levels[i]);
             g_cache[s].stamp = ++g_stamp;
             ++g_hits;
             return g_cache[s].ptr;
@@ -262,11 +274,15 @@ static SEXP cached_handle(SEXP data, SEXP cfd_factors, SEXP cfd_indicators, SEXP
         handle_finalizer(g_cache[victim].ptr);
         R_ReleaseObject(g_cache[victim].ptr);
         g_cache[victim].ptr = NULL;
+        free(g_cache[victim].n_levels);
+        g_cache[victim].n_levels = NULL;
     }
     SEXP ptr = insider_hip_create_R(data, cfd_factors, cfd_indicators, ctns_confounder, train_indicator, test_indicator,
                                     inc_continuous, latent_dim, device);
     if (ptr == R_NilValue) return ptr;
     R_PreserveObject(ptr);
+    g_cache[victim].n_levels = (int *)malloc(sizeof(int) * (size_t)(c > 0 ? c : 1));
+    for (int i = 0; i < c && g_cache[victim].n_levels; i++) g_cache[victim].n_levels[i] = Rf_nrows(VECTOR_ELT(cfd_factors, i));
     g_cache[victim].data = kd; g_cache[victim].lev = kl; g_cache[victim].train = ktr; g_cache[victim].test = kte;
     g_cache[victim].ctns = kc; g_cache[victim].n = n; g_cache[victim].p = p; g_cache[victim].c = c; g_cache[victim].inc = inc;
     g_cache[victim].device = dev; g_cache[victim].ptr = ptr; g_cache[victim].stamp = ++g_stamp;

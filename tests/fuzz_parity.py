@@ -64,6 +64,8 @@ def draw_case(rng):
 def tolerances(case):
     tol = 1e-6 if case["m"] else 1e-7   # the continuous update solves an m x m system whose conditioning the data sets
     tol_traj = 1e-8
+    if os.environ.get("FUZZ_TIGHT"):   # hunting mode: the suite's base tolerances for every case (finds the rounding-level outliers
+        return tol, tol_traj           # that tests/golden/fuzz_outliers.json freezes)
     if case["sub_tol"] < 1e-9:      # the stopping rule |dloss| <= 1e-11 on losses of 1e3 is decided at rounding level: a sweep more
         tol = 5e-6                  # or less on either side moves beta by ~sqrt(tol / D).  (A 3000-case sweep in round 3 had 3 cases
         tol_traj = 1e-7             # of this regime just outside 1e-6 / 1e-8: factors 1.2e-6, trajectories 1.4e-8 and 1.6e-8.)
@@ -131,7 +133,9 @@ def run_oracle(case, iters=None, want_sweeps=False):
 
 def errors(got, ref):
     """(row, column, trajectory) relative deviations of a HIP result from the oracle's."""
-    e_row = max(relerr(got["row_matrices"][f"factor{i}"], a) for i, a in enumerate(ref["row_matrices"]))
+    rm = ref["row_matrices"]
+    rm = [rm[f"factor{i}"] for i in range(len(rm))] if isinstance(rm, dict) else rm     # (another HIP result as the reference)
+    e_row = max(relerr(got["row_matrices"][f"factor{i}"], a) for i, a in enumerate(rm))
     e_col = relerr(got["column_factor"], ref["column_factor"])
     tg, tr = got["traj"][:, 1:8], ref["traj"][:, 1:8]
     e_traj = (float(np.nanmax(np.abs(tg - tr) / np.maximum(np.abs(tr), 1e-300))) if tg.shape == tr.shape and tg.size

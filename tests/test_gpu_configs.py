@@ -12,6 +12,8 @@
 Tolerances as tests/test_gpu_parity.py (fp64): one iteration rel 1e-9 on the factors, several iterations rel 1e-6,
 loss trajectory rel 1e-9.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -223,3 +225,53 @@ def test_c4_full_size_properties():
     if free < 40e9:      # X (16 GB) + two masks + the generator's blocks + the residual check: do not drive a small host out of memory
         pytest.skip(f"needs ~40 GB of free host memory, {free / 1e9:.0f} GB available")
     _full_size_properties("c4", 11, compare_lists=False)
+
+
+def test_c3_structure_full_n_slab_with_continuous_covariates_vs_oracle():
+    """Continuous covariates at real size (optimize_continuous_v2, src/optimize.cpp:76-137,340-351): c3's
+    structure at full n (10000 samples, 100 x 10 levels, K = 30, 10 % held out), a 192-gene slab, plus TWO N(0, 1) columns
+    of ctns_confounder — one outer iteration from a non-trivial start (factors 1e-9) and three from the cold inits (1e-6,
+    trajectory 1e-9) against the oracle's literal scalar passes over the n x p residual."""
+    from oracle import c_oracle
+    w = workloads.make("c3", gene_range=(0, SLAB_GENES))
+    m = 2
+    Z = np.asfortranarray(np.random.default_rng(77).standard_normal((w.n, m)))
+    rng = np.random.default_rng(5)
+    A1 = [np.asfortranarray(rng.standard_normal(a.shape) * 0.3) for a in w.A0] + [np.asfortranarray(rng.standard_normal((m, w.K)) * 0.3)]
+    C1 = np.asfortranarray(rng.standard_normal(w.C0.shape) * 0.3)
+    A0 = [a.copy(order="F") for a in w.A0] + [np.asfortranarray(np.random.default_rng(9).standard_normal((m, w.K)) * 1e-3)]
+    c_oracle.set_col_chunk(1)
+    try:
+        # the cores this process may really use (affinity, cgroup quota): the continuous update's scalar passes are barrier-bound,
+        # and an OpenMP team larger than the CPU share (omp_get_num_procs sees the whole host) spins for minutes
+        threads = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                threads = min(threads, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+        threads = max(1, min(threads, 16))
+        ref1 = c_oracle.optimize(w.X, w.levels, w.n_levels, A1, C1, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1, max_iter=0,
+                                 seed=17, max_sweeps=SWEEP_CAP, col_threads=threads, row_threads=threads, ctns=Z)
+        ref4 = c_oracle.optimize(w.X, w.levels, w.n_levels, A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1, max_iter=2,
+                                 seed=23, max_sweeps=SWEEP_CAP, col_threads=threads, row_threads=threads, ctns=Z)
+    finally:
+        c_oracle.set_col_chunk(100)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
+    ds.set_option("max_sweeps", SWEEP_CAP)
+    got = ds.optimize([a.copy(order="F") for a in A1], C1.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=0, seed=17,
+                      inc_continuous=1)
+    assert len(ref1["row_matrices"]) == 3
+    for i, a in enumerate(ref1["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-9, i
+    assert relerr(got["column_factor"], ref1["column_factor"]) < 1e-9
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref1["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+    got = ds.optimize([a.copy(order="F") for a in A0], w.C0.copy(order="F"), w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=2, seed=23,
+                      inc_continuous=1)
+    ds.close()
+    assert got["iters"] == ref4["iters"] == 3
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref4["traj"][:, 1:8], rtol=1e-9, equal_nan=True)
+    for i, a in enumerate(ref4["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-6, i
+    assert relerr(got["column_factor"], ref4["column_factor"]) < 1e-6

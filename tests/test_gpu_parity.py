@@ -349,7 +349,7 @@ def test_multipass_column_solve_is_bit_identical(oracle, K, limits):
 
 @pytest.mark.parametrize("K,frac", [(12, 0.03), (30, 0.1), (20, 0.25), (30, 0.001)])
 def test_split_column_step_is_bit_identical(oracle, K, frac):
-    """Steady-state outer iterations run the column step split (option cd_split, default on): the genes predicted longest —
+    """Steady-state outer iterations can run the column step split (option cd_split = 2; OFF by default): the genes predicted longest —
     whole buckets of the launch order, at most cd_long_frac of the genes — get their statistics and their solve on a stream of
     their own, ahead of the statistics of everyone else.  Every gene's record and solve are the same computations as in the
     unsplit step, so factors, trajectory and sweep counts must be bit-identical (and agree with the oracle)."""

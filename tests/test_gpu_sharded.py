@@ -161,19 +161,46 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
         assert key in two and two["roofline"]["frac"] <= 1.0
 
 
+def test_bench_grid_parallel_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2 --grid`: config 3's 40 grid points dealt over the ranks (every rank keeps the whole c3 data set
+    resident, api.tune(rank, world), one all-reduce of the result table), reported as the `grid_parallel` block next to the
+    unchanged strong-scaling line.  Rehearsed with two ranks on the one GPU (gloo): the table equals the one-process grid's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["INSIDER_BENCH_ONE_GPU"] = "1"
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--grid", "--workload", "c2", "--steps", "4",
+                         "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    gp = two["grid_parallel"]
+    assert "failed" not in gp, gp
+    assert gp["points"] == 40 and gp["points_per_rank"] == 20 and gp["table_complete"] and gp["mean_outer_iterations_per_s"] > 0
+    assert two["n_gpus"] == 2 and "2000 x 20000" in two["metric"]          # the strong-scaling line itself is unchanged
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--grid", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                        cwd=root, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    np.testing.assert_array_equal(np.array(gp["table"]), np.array(one["grid"]["table"]))
+
+
 # ---- grid-parallel tune() on real handles (SURVEY.md 8f N1): every rank keeps the WHOLE data set resident on the GPU and
 # fits the grid points g % world == rank; the result tables are summed over torch.distributed -----------------------------
 TUNE_CASE = dict(n=96, p=140, level_counts=(6, 4), K=6, f=0.15, seed=31)
 
 
-def _tune_real(rank, world, warm_start=False):
+def _tune_real(rank, world, warm_start=False, concurrent=1):
     from insider_amd import api
     w = workloads.small(**TUNE_CASE)
     obj = api.Insider(data=w.X, confounder=w.levels, inc_continuous=0, ctns_confounder=None, train_indicator=w.M_train,
                       test_indicator=w.M_test, seed=13,
                       params=dict(global_tol=1e-9, sub_tol=1e-5, tuning_iter=6, max_iter=50))
     out = api.tune(obj, latent_dimension=np.array([4, 6]), lambda_=[1.0, 2.0, 4.0], alpha=[0.2, 0.5],
-                   rng=np.random.default_rng(5), rank=rank, world=world, warm_start=warm_start)
+                   rng=np.random.default_rng(5), rank=rank, world=world, warm_start=warm_start, concurrent=concurrent)
+    for hd in obj.get("_tune_clones", []):
+        hd.close()
     obj["_resident_tune"].close()
     return out
 
@@ -229,3 +256,64 @@ def test_tune_warm_start_is_opt_in_and_close_to_cold():
     assert not np.array_equal(warm["reg_tuning"][1:], cold["reg_tuning"][1:])
     # within the same iteration budget a warm-started point is further along than a cold one: lower train RMSE
     assert np.all(warm["reg_tuning"][1:, 2] < cold["reg_tuning"][1:, 2]) and np.all(np.isfinite(warm["reg_tuning"]))
+
+
+# ---- several fits of one resident data set at the same time (insider_hip_clone) ----------------------
+def test_concurrent_tune_is_bit_identical():
+    """tune(concurrent=3): three grid points at a time on the one GPU, each on its own handle of the shared data set, from
+    three host threads.  The tables equal the serial grid's to the last bit: the inits are drawn by one generator in the
+    reference's order and a fit does not depend on the handle that runs it or on what runs beside it."""
+    serial = _tune_real(0, 1)
+    conc = _tune_real(0, 1, concurrent=3)
+    np.testing.assert_array_equal(conc["rank_tuning"], serial["rank_tuning"])
+    np.testing.assert_array_equal(conc["reg_tuning"], serial["reg_tuning"])
+    with pytest.raises(ValueError):
+        _tune_real(0, 1, warm_start=True, concurrent=2)
+
+
+def test_clones_share_the_data_set_and_outlive_their_source():
+    """insider_hip_clone: same resident device arrays, private workspace.  Four threads fit four different (lambda, K)
+    points at once on the source and three clones; each result is bit-identical to the same fit run alone, and a clone keeps
+    working after its source handle has been destroyed (the data set goes with the LAST handle)."""
+    import threading
+    from insider_amd import api
+    w = workloads.small(n=150, p=400, level_counts=(7, 5), K=12, f=0.12, seed=77, with_na=True)
+    points = [(1.0, 12), (3.0, 12), (5.0, 9), (2.0, 17)]
+
+    def inits(K, seed):
+        rs = np.random.default_rng(seed)
+        A = [np.asfortranarray(rs.standard_normal((int(L), K)) * 1e-3) for L in w.n_levels]
+        return A, np.asfortranarray(rs.standard_normal((K, w.p)) * 1e-3)
+
+    def fit(hd, lam, K):
+        A, C = inits(K, K)
+        return hd.optimize(A, C, K, lam, lam, 0.4, tuning=1, max_iter=12, seed=3)
+
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    alone = [fit(ds, lam, K) for lam, K in points]
+    handles = [ds] + [ds.clone() for _ in range(3)]
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):          # repeated: the fits overlap in different phases
+                out[i] = fit(handles[i], *points[i])
+        except Exception as e:
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for got, ref in zip(out, alone):
+        assert np.array_equal(got["column_factor"], ref["column_factor"]) and got["loss"] == ref["loss"]
+        for k in ref["row_matrices"]:
+            assert np.array_equal(got["row_matrices"][k], ref["row_matrices"][k])
+        assert np.array_equal(got["traj"], ref["traj"], equal_nan=True)
+    ds.close()                          # the source goes first
+    again = fit(handles[1], *points[0])
+    assert np.array_equal(again["column_factor"], alone[0]["column_factor"])
+    for hd in handles[1:]:
+        hd.close()

@@ -106,6 +106,8 @@ def test_registered_routines_match_the_r_wrappers(shim):
         for m in re.finditer(r'\.Call\("%s"((?:[^()]|\([^()]*\))*)\)' % name, rsrc):
             args = [a for a in m.group(1).split(",") if a.strip()]
             assert len(args) == n, (name, args)
+    # the wrapper's CPU fall-back is announced, not silent (K > 63, no device: the shim warns, the wrapper adds a message)
+    assert 'message("insider_hip: optimize() runs on the CPU reference' in rsrc
 
 
 def _problem(r, seed=3, n=48, p=80, levels=(6, 4), K=5):
@@ -188,6 +190,11 @@ def test_tune_style_calls_reuse_one_resident_handle_and_match_ctypes(shim):
     ds.close()
     st = r.to_numpy(r.call("insider_hip_cache_stats_R"), (3,)) - base
     assert st[0] == 2 and st[1] == 1 and st[2] == 1                  # one upload, two re-uses, one live handle
+    # a cache hit with factor matrices of ANOTHER row count (the handle's level counts came from the first call's): an R error,
+    # not an out-of-bounds read of the caller's matrices
+    bad = [r.real(np.zeros((a.shape[0] + (1 if i == 0 else 0), w.K))) for i, a in enumerate(w.A0)]
+    with pytest.raises(RuntimeError, match="was created with"):
+        r.call("insider_hip_optimize_R", *_optimize_args(r, w, sx, bad, r.real(w.C0), 2.0))
     # another data object (what R's copy-on-modify produces when the user changes the matrix): a second handle
     sx2 = dict(sx, data=r.real(w.X * 1.0))
     out = r.call("insider_hip_optimize_R", *_optimize_args(r, w, sx2, [r.real(a) for a in w.A0], r.real(w.C0), 2.0))
@@ -207,7 +214,9 @@ def test_tune_style_calls_reuse_one_resident_handle_and_match_ctypes(shim):
     K = 64
     Abig = [r.real(np.zeros((a.shape[0], K))) for a in w.A0]
     out = r.call("insider_hip_optimize_R", *_optimize_args(r, w, sx, Abig, r.real(np.zeros((K, w.C0.shape[1]))), 2.0, K=K))
-    assert shim.mock_is_nil(out) and b"CPU reference" in shim.mock_last_warning()
+    # the fallback is VISIBLE: the warning names the status, the reason (the library's K range) and what happens next
+    wtxt = shim.mock_last_warning()
+    assert shim.mock_is_nil(out) and b"CPU reference" in wtxt and b"K must be in 1..63" in wtxt and b"status 6" in wtxt, wtxt
     r.call("insider_hip_cache_clear_R")
     assert shim.mock_preserved_count() == 0
     assert r.to_numpy(r.call("insider_hip_cache_stats_R"), (3,))[2] == 0
