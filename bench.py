@@ -25,6 +25,8 @@ Prints ONE JSON line on rank 0:
   cpu_baseline  the CPU oracle (reference formulation) on a bounded gene sample, all host threads engaged
   grid          (--grid) BASELINE config 3 as written: tune() over lambda in {1,3,..,19} x alpha in {.2,.3,.4,.5}
 """
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything initialises the HIP runtime (see insider_amd/_lib.py: concurrent fits)
 import argparse
 import hashlib
 import json
@@ -136,6 +138,22 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
                           "fixed_ms_per_gene": per_gene_fixed * 1e3, "sweep_ms_per_gene_sweep": per_gene_sweep * 1e3,
                           "sample_wall_s": wall, "sample_cpu_s": cpu, "cpu_over_wall": cpu / wall,
                           "sample_sweeps": int(res["total_sweeps"])}
+        # LIVE check of the model behind the extrapolation, in this run, on this box: the same sample with three times the
+        # sweep cap — a different split between the per-gene and the per-sweep cost — timed and compared with what the two
+        # parameters fitted above predict for ITS sweep count
+        live = None
+        try:
+            m0 = out["reference_threads"]
+            c_oracle.set_cd_form(0)
+            t0 = time.perf_counter()
+            res = c_oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, lam, lam, alpha, tuning=w.tuning,
+                                    max_iter=0, seed=1, row_threads=m0["row_threads"], col_threads=m0["col_threads"], max_sweeps=3 * cap)
+            wall = time.perf_counter() - t0
+            pred = genes * m0["fixed_ms_per_gene"] * 1e-3 + res["total_sweeps"] * m0["sweep_ms_per_gene_sweep"] * 1e-3
+            live = {"sample": f"the same {genes} genes, 1 outer iteration, sweeps capped at {3 * cap}", "sweeps": int(res["total_sweeps"]),
+                    "measured_wall_s": wall, "model_wall_s": pred, "measured_over_model": wall / pred}
+        except Exception as e:
+            live = {"failed": repr(e)}
     finally:
         c_oracle.set_col_chunk(100)
         c_oracle.set_cd_form(0)
@@ -145,7 +163,7 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
     check = None
     try:
         mc = json.load(open(os.path.join(ROOT, "profiles", "r03", "cpu_model_check.json")))
-        check = {"source": "profiles/r03/cpu_model_check.json (tools/cpu_validate.py)", "cpu_model": mc.get("cpu_model"),
+        check = {"source": "profiles/r03/cpu_model_check.json (tools/cpu_validate.py; RECORDED in round 3 on another box, not measured in this run)", "cpu_model": mc.get("cpu_model"),
                  "nproc": mc.get("nproc")}
         for key in ("c2_full", "c3_slab"):
             if key in mc:
@@ -153,7 +171,8 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
                                                       "model_wall_s", "measured_over_model") if k in mc[key]}
     except Exception:
         pass
-    return {"value": main["value"], "unit": "outer-iterations/s", "cores": main["col_threads"], "kind": "port", "model_check": check,
+    return {"value": main["value"], "unit": "outer-iterations/s", "cores": main["col_threads"], "kind": "port", "model_check_live": live,
+            "model_check": check,
             "sample": (f"{name}: first {genes} of {cp} genes x all {cn} samples, 1 outer iteration, sweeps capped at {cap}, "
                        f"gene-loop chunk 1; {main['sample_wall_s']:.1f} s wall, cpu-time/wall {main['cpu_over_wall']:.1f} "
                        f"(row step {main['row_threads']} / column step {main['col_threads']} threads; the reference hard-codes "
@@ -541,7 +560,7 @@ def main():
                     gc_ = grid_bench(ds, w, K, args.steps, concurrent=args.concurrent)
                     for hd in gc_.pop("_clones"):
                         hd.close()
-                    gc_["identical_to_serial_grid"] = bool(np.array_equal(np.array(gc_.pop("table")), np.array(out["grid"]["table"])))
+                    gc_["identical_to_serial_grid"] = bool(np.array_equal(np.array(gc_.pop("table")), np.array(out["grid"]["table"]), equal_nan=True))
                     gc_["speedup_vs_serial_grid"] = out["grid"]["wall_s"] / gc_["wall_s"]
                     out["grid_concurrent"] = gc_
                 # opt-in extension (NOT the reference's behaviour): every grid point starts from its nearest finished neighbour

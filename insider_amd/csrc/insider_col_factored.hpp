@@ -27,8 +27,8 @@ struct ColFacArgs {
     size_t plane;                         // entries per plane of slev
     const uint32_t *grp[CF_MAXC];         // position t (descending level count): [p][L + 1]
     const uint16_t *slev[CF_MAXC];        // its planes (stacked level of every other covariate, covariate order)
-    int L[CF_MAXC], off[CF_MAXC];         // levels and stacked offset of the covariate at position t
-    int nlater[CF_MAXC];
+    int L[CF_MAXC + 1], off[CF_MAXC + 1]; // levels and stacked offset of the covariate at position t (position c: the
+    int nlater[CF_MAXC + 1];              // continuous columns as one pseudo-covariate of m "levels", see zt)
     int later_plane[CF_MAXC][CF_MAXC];    // plane index inside slev[t] of each later covariate
     int tab_skip_lo, tab_skip_n;          // stacked levels [lo, lo + n) (position 0) are not in the LDS table
     int tab_rows;                         // SLcat - tab_skip_n
@@ -42,12 +42,23 @@ struct ColFacArgs {
     // [l / 16][lane = (q % 4) * 16 + l % 16][q / 4] with 4 or 8 bytes per lane (one dword / two dwords per lane and
     // block of 16 levels); static per data set (mask and levels only)
     const uint8_t *cnt;
-    int cnt_stride, cnt_off[CF_MAXC], nsteps;   // bytes per gene, offset of position t, ceil(tab_rows / 4)
+    int cnt_stride, cnt_off[CF_MAXC + 1], nsteps;   // bytes per gene, offset of position t, ceil(tab_rows / 4)
     // 1/2 n_j(l), the held-out entries of gene j in level l of the covariate at position t, as floats in the order the
     // kernel's lanes want them: [block of 16 levels][l % 4][(l % 16) / 4] (lane quarter g4 reads the four levels g4 + 4 s
     // of a block as one 16-byte word), zero beyond the last level; static per data set (k_half_counts)
     const float *hn;
-    int hn_stride, hn_off[CF_MAXC];             // floats per gene, offset of position t
+    int hn_stride, hn_off[CF_MAXC + 1];         // floats per gene, offset of position t
+    // continuous covariates (ctns_confounder, m <= 4 columns; optimize_continuous_v2, src/optimize.cpp:76-137) on the same
+    // form: with r_i = t_i + A_c' z_i (t_i the categorical part) the complement sum_{i in H(j)} r_i r_i' gains the cross terms
+    // sum_l a_l zeta_jl' A_c + transpose, zeta_jl = sum_{i in l ∩ H(j)} z_i, and A_c' ZZ_j A_c, ZZ_j = sum_{i in H(j)} z_i z_i'.
+    // Both are more count products: the continuous columns are table rows that come AFTER every categorical covariate, with
+    // REAL-valued counts zeta_jl (so p_jl += A_c' zeta_jl), and they are one more position (c) of m pseudo-levels whose
+    // p_k = sum_k' (1/2 ZZ_j[k][k']) a^c_k'.  zt holds those counts per gene in MFMA A-operand order, one k-step of four table
+    // rows: [position offset + block of 16 levels][lane = k * 16 + l % 16]; static per data set (k_zt_build).  null: none.
+    const double *zt;
+    int zt_stride, zt_off[CF_MAXC + 1];         // doubles per gene, offset of position t
+    int m, SLcat;                               // continuous columns; their factor rows are Astack[SLcat .. SLcat + m)
+    int pos_cov[CF_MAXC];                       // covariate (column of the level table) at position t
     // split solves (k_col_paircnt): the long genes' records are formed first, from their list, so that their solve can start
     // while the statistics of the others are still running; the launch over all genes then skips them
     const int *list;                      // gene ids of this launch (null: all genes 0 .. p-1)
@@ -209,6 +220,7 @@ struct PairBlk {          // operands of one block of 16 levels, raw as fetched 
     uint32_t cw[2];       // this lane's count bytes (k-step s = byte s)
     float4 hn;            // 1/2 n of levels l0 + 4 s + g4, s = 0 .. 3 (0 beyond the last level)
     double av[4][NB];     // factor rows: k-step s holds level l0 + 4 s + g4, component 16 bb + c16
+    double z;             // real-valued count of (level l0 + c16, continuous column g4) (ZC instantiation only)
 };
 
 // Round 3: every vector instruction of this kernel costs f64-MFMA issue time (section 4 of DESIGN.md), and a block of 16 levels
@@ -220,7 +232,10 @@ struct PairBlk {          // operands of one block of 16 levels, raw as fetched 
 //  * 1/2 n comes from a static float table laid out for one 16-byte load per lane and block (ColFacArgs::hn);
 //  * every address is a wave-uniform base (scalar arithmetic) plus a lane offset that never changes;
 //  * the table operand of the count product lives in registers for the whole gene (2 x nsteps doubles per lane).
-template <int NB, int WPB>
+// ZC: the data set has continuous covariates (ColFacArgs::zt): one more k-step per block of 16 levels with real-valued
+// counts, and one more position for the continuous columns themselves.  A separate instantiation: the categorical-only
+// kernel keeps its register allocation.
+template <int NB, int WPB, bool ZC = false>
 __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
 {
     constexpr int KP = Geo<NB>::KP;
@@ -256,6 +271,10 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
     for (int s = 0; s < CP_MAXSTEPS; ++s)
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) tb[s][bb] = s < a.nsteps ? tabs[(4 * s + g4) * KP + 16 * bb + c16] : 0.0;
+    // B operand of the real-count product: the factor row of continuous column g4 (rows beyond m: the table's zero padding)
+    double tbz[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) tbz[bb] = ZC ? a.Astack[(size_t)(a.SLcat + g4) * KP + 16 * bb + c16] : 0.0;
     d4 acc[NB][NB];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi)
@@ -263,14 +282,18 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
         for (int bj = 0; bj < NB; ++bj) acc[bi][bj] = d4{0.0, 0.0, 0.0, 0.0};
     const uint8_t *cj = a.cnt + (size_t)j * a.cnt_stride;
     const float *hj = a.hn + (size_t)j * a.hn_stride;
+    const double *zj = ZC ? a.zt + (size_t)j * a.zt_stride : nullptr;
     const unsigned off_c = (unsigned)lane * (unsigned)bpl, off_h = (unsigned)g4 * 4u, off_a = (unsigned)(g4 * KP + c16);
-    for (int t = 0; t < a.c; ++t) {
+    const int npos = a.c + (ZC ? 1 : 0);
+    for (int t = 0; t < npos; ++t) {
         const int Lo = a.L[t];
         const bool cross = a.nlater[t] > 0;   // wave-uniform
         const uint8_t *ct = cj + a.cnt_off[t];
         const float *ht = hj + a.hn_off[t];
         const double *At = a.Astack + (size_t)a.off[t] * KP;
+        const double *zt = ZC ? zj + a.zt_off[t] : nullptr;
         auto fetch = [&](int l0, PairBlk<NB> &b) {
+            if constexpr (ZC) b.z = zt[(size_t)(l0 >> 4) * 64 + lane];
             b.cw[0] = b.cw[1] = 0;
             if (cross) {
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + (size_t)(l0 >> 4) * 64 * bpl + off_c);
@@ -298,6 +321,10 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
                         for (int bb = 0; bb < NB; ++bb)
                             P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv, tb[s][bb], P[bb], 0, 0, 0);
                     }
+            }
+            if constexpr (ZC) {
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.z, tbz[bb], P[bb], 0, 0, 0);
             }
             const double hn[4] = {(double)cur.hn.x, (double)cur.hn.y, (double)cur.hn.z, (double)cur.hn.w};
 #pragma unroll
@@ -327,6 +354,66 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
         }
     }
     cf_store<NB, true>(acc, tr, a, j, lane, rtr, qh, ss);
+}
+
+// The real-valued count table of the continuous covariates (ColFacArgs::zt) and the held-out sums sum_{i in H(j)} x_ij z_ik,
+// once per data set.  One wave per gene; every sum runs over the gene's held-out list in list order (fixed order:
+// reproducible), each lane owning the levels l = lane, lane + 64, ... of a position.  lev: [c][n] zero-based levels; Zc: [m][n].
+__global__ void __launch_bounds__(256) k_zt_build(ColFacArgs a, const uint32_t *__restrict__ col_ptr, const int *__restrict__ col_idx,
+                                                  const double *__restrict__ col_val, const int *__restrict__ lev,
+                                                  const double *__restrict__ Zc, int n, double *__restrict__ zt,
+                                                  double *__restrict__ xz /*[p][xz_pitch], columns SLcat ..*/, int xz_pitch,
+                                                  const double *__restrict__ S_all, double *__restrict__ S_train /*same pitch*/)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + w;
+    if (j >= a.p) return;
+    const uint32_t eb = col_ptr[j], ee = col_ptr[j + 1];
+    double *zo = zt + (size_t)j * a.zt_stride;
+    for (int t = 0; t < a.c; ++t) {
+        const int *lv = lev + (size_t)a.pos_cov[t] * n;
+        for (int l = lane; l < a.L[t]; l += WAVE) {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (uint32_t e = eb; e < ee; ++e) {
+                const int i = col_idx[e];
+                if (i < n && lv[i] == l) {      // (list padding carries an index beyond n)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < a.m) s[k] += Zc[(size_t)k * n + i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zo[a.zt_off[t] + (l >> 4) * 64 + k * 16 + (l & 15)] = s[k];
+        }
+    }
+    // position c: 1/2 ZZ_j[k][k'] at lane k' * 16 + k;  the held-out sums of x z
+    if (lane < 16) {
+        const int k = lane & 3, k2 = lane >> 2;
+        double zz = 0.0, sx = 0.0;
+        for (uint32_t e = eb; e < ee; ++e) {
+            const int i = col_idx[e];
+            if (i < n && k < a.m && k2 < a.m) {
+                const double zk = Zc[(size_t)k * n + i];
+                zz += zk * Zc[(size_t)k2 * n + i];
+                if (k2 == 0) sx += col_val[e] * zk;
+            }
+        }
+        if (k < a.m && k2 < a.m) zo[a.zt_off[a.c] + k2 * 16 + k] = 0.5 * zz;
+        if (k2 == 0 && k < a.m) {
+            xz[(size_t)j * xz_pitch + a.SLcat + k] = sx;
+            // the train-entry sums of x z (merged row update of a continuous column): all entries minus the held-out ones
+            S_train[(size_t)j * xz_pitch + a.SLcat + k] = S_all[(size_t)j * xz_pitch + a.SLcat + k] - sx;
+        }
+    }
+}
+
+// weights of continuous column k as a one-level covariate of the merged row update: w_j = sum_{i in H(j)} z_ik^2 = 2 x the
+// stored 1/2 ZZ_j[k][k]
+__global__ void __launch_bounds__(256) k_cont_weights(const double *__restrict__ zt, int zt_stride, int zt_off_c, int k, int p,
+                                                      double *__restrict__ w)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < p) w[j] = 2.0 * zt[(size_t)j * zt_stride + zt_off_c + k * 16 + k];
 }
 
 // 1/2 n_j(l) in the kernel's order (ColFacArgs::hn); once per data set.  One thread per (gene, padded level).
@@ -400,15 +487,16 @@ __global__ void __launch_bounds__(WPB * 64) k_pair_count_build(ColFacArgs a, uin
 //        + sum_{t' < t} sum_{l'} n^{t'}_j(l', column of (t, l)) V_j[level l' of t']  (the tables of the covariates before it,
 //                                                                                     read transposed).
 // One wave per gene, ~20 instructions per block of 16 levels instead of one look-up per held-out entry and other covariate.
+constexpr int GU_BATCH = 8;   // blocks of 16 levels whose partial sums share one trip through LDS (k_gene_u_cnt)
 template <int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, int LP, const double *__restrict__ V, int SLP,
                                                          int SL, double *__restrict__ U)
 {
-    extern __shared__ double s_uc[];   // per wave: V row [SL] | out [LP] | 64 partials
+    extern __shared__ double s_uc[];   // per wave: V row [SL] | out [LP] | GU_BATCH x 64 partials
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * WPB + w;
     if (j >= a.p) return;
-    double *v = s_uc + (size_t)w * (SL + LP + WAVE), *out = v + SL, *red = out + LP;
+    double *v = s_uc + (size_t)w * (SL + LP + GU_BATCH * WAVE), *out = v + SL, *red = out + LP;
     const int Lt = a.L[t];
     // the gene's row of V, without the covariate's own columns (never read: u sums over the OTHER covariates)
     for (int q = lane; q < SL; q += WAVE) v[q] = (q < a.off[t] || q >= a.off[t] + Lt) ? V[(size_t)j * SLP + q] : 0.0;
@@ -426,17 +514,35 @@ __global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, in
             vq[s] = (s < a.nsteps && r < a.tab_rows) ? v[q] : 0.0;
         }
         const uint8_t *ct = cj + a.cnt_off[t];
-        for (int l0 = 0; l0 < Lt; l0 += 16) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)(l0 >> 4) * 64 + lane) * bpl);
-            uint32_t cw[2] = {src[0], bpl == 8 ? src[1] : 0u};
-            double part = 0.0;
+        // GU_BATCH blocks of 16 levels at a time (round 4): their count loads are issued together and their partial sums make ONE
+        // trip through LDS — one block per trip left seven dependent global loads and fourteen wave syncs per gene at c3.  The
+        // sum of a level's four partials keeps its order: bit-identical results.
+        for (int l0 = 0; l0 < Lt; l0 += 16 * GU_BATCH) {
+            uint32_t cw[GU_BATCH][2];
 #pragma unroll
-            for (int s = 0; s < CP_MAXSTEPS; ++s)
-                if (s < a.nsteps)   // wave-uniform: the table's k-steps only
-                    part = fma((double)((cw[s >> 2] >> (8 * (s & 3))) & 0xffu), vq[s], part);
-            red[lane] = part;
+            for (int bq = 0; bq < GU_BATCH; ++bq) {
+                cw[bq][0] = cw[bq][1] = 0u;
+                if (l0 + 16 * bq < Lt) {   // wave-uniform
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)((l0 >> 4) + bq) * 64 + lane) * bpl);
+                    cw[bq][0] = src[0];
+                    if (bpl == 8) cw[bq][1] = src[1];
+                }
+            }
+#pragma unroll
+            for (int bq = 0; bq < GU_BATCH; ++bq)
+                if (l0 + 16 * bq < Lt) {
+                    double part = 0.0;
+#pragma unroll
+                    for (int s = 0; s < CP_MAXSTEPS; ++s)
+                        if (s < a.nsteps)   // wave-uniform: the table's k-steps only
+                            part = fma((double)((cw[bq][s >> 2] >> (8 * (s & 3))) & 0xffu), vq[s], part);
+                    red[64 * bq + lane] = part;
+                }
             wave_sync();
-            if (g4 == 0 && l0 + c16 < Lt) out[l0 + c16] = ((red[c16] + red[16 + c16]) + red[32 + c16]) + red[48 + c16];
+            for (int x = lane; x < 16 * GU_BATCH && l0 + x < Lt; x += WAVE) {
+                const double *r = red + 64 * (x >> 4) + (x & 15);
+                out[l0 + x] = ((r[0] + r[16]) + r[32]) + r[48];
+            }
             wave_sync();
         }
     }
@@ -446,9 +552,15 @@ __global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, in
         double acc[CP_MAXSTEPS];
 #pragma unroll
         for (int s = 0; s < CP_MAXSTEPS; ++s) acc[s] = 0.0;
+        const uint32_t *src0 = reinterpret_cast<const uint32_t *>(ct + (size_t)lane * bpl);
+        uint32_t nx[2] = {src0[0], bpl == 8 ? src0[1] : 0u};
         for (int l0 = 0; l0 < Lp; l0 += 16) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)(l0 >> 4) * 64 + lane) * bpl);
-            uint32_t cw[2] = {src[0], bpl == 8 ? src[1] : 0u};
+            const uint32_t cw[2] = {nx[0], nx[1]};
+            if (l0 + 16 < Lp) {   // the next block's counts fly during this block's FMAs
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + ((size_t)((l0 >> 4) + 1) * 64 + lane) * bpl);
+                nx[0] = src[0];
+                if (bpl == 8) nx[1] = src[1];
+            }
             const double vv = l0 + c16 < Lp ? v[a.off[tp] + l0 + c16] : 0.0;
 #pragma unroll
             for (int s = 0; s < CP_MAXSTEPS; ++s)
@@ -466,7 +578,35 @@ __global__ void __launch_bounds__(WPB * 64) k_gene_u_cnt(ColFacArgs a, int t, in
         wave_sync();
     }
     wave_sync();
+    if (a.zt) {   // continuous covariates: + sum_k zeta_j[l][k] V_j[SLcat + k]  (s_r carries A_c' z_r; ColFacArgs::zt)
+        const double *zr = a.zt + (size_t)j * a.zt_stride + a.zt_off[t];
+        for (int l = lane; l < Lt; l += WAVE) {
+            double sacc = out[l];
+            for (int k = 0; k < a.m; ++k) sacc = fma(zr[(l >> 4) * 64 + k * 16 + (l & 15)], v[a.SLcat + k], sacc);
+            out[l] = sacc;
+        }
+        wave_sync();
+    }
     for (int l = lane; l < LP; l += WAVE) U[(size_t)j * LP + l] = l < Lt ? out[l] : 0.0;
+}
+
+// The same quantity for CONTINUOUS column k as a one-level covariate with real-valued membership weights z_rk
+// (optimize_continuous_v2, src/optimize.cpp:76-137, on the merged form): u_j = c_j' sum_{r in H(j)} z_rk s_r with s_r the
+// row factor without column k's own contribution = sum_l V_j[l] zeta_j[l][k] over every categorical level
+// + sum_{k' != k} ZZ_j[k][k'] V_j[SLcat + k'].  One wave per gene, fixed summation order.  U: [p][2].
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_gene_uc(ColFacArgs a, int k, const double *__restrict__ V, int SLP, double *__restrict__ U)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * WPB + w;
+    if (j >= a.p) return;
+    const double *zr = a.zt + (size_t)j * a.zt_stride, *vj = V + (size_t)j * SLP;
+    double s = 0.0;
+    for (int t = 0; t < a.c; ++t)
+        for (int l = lane; l < a.L[t]; l += WAVE) s = fma(zr[a.zt_off[t] + (l >> 4) * 64 + k * 16 + (l & 15)], vj[a.off[t] + l], s);
+    if (lane < a.m && lane != k) s = fma(2.0 * zr[a.zt_off[a.c] + lane * 16 + k], vj[a.SLcat + lane], s);
+    s = group_sum<64>(s, lane);
+    if (lane == 0) { U[(size_t)j * 2] = s; U[(size_t)j * 2 + 1] = 0.0; }
 }
 
 // Sheld = S - Strain (once per data set)

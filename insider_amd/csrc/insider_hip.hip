@@ -113,6 +113,8 @@ struct insider_hip_handle {
     hipStream_t side3 = nullptr;      // C'C and (S^train C') of the merged row update, next to the weighted SYRK
     hipEvent_t ev_prep = nullptr;
     hipEvent_t ev_c_ready = nullptr;
+    hipEvent_t ev_head = nullptr;     // recorded on side2 in front of the level Gram GEMM: the main chain's k_gene_u waits for it
+    int row_head = 1;                 // option "row_head": that wait (1 = on)
     std::vector<hipEvent_t> ev_w;
     double *lvl_sum_all = nullptr;    // [SLcat][STAT + 2 KP + 2]: the level records of every covariate
     bool w_ready = false;
@@ -131,6 +133,12 @@ struct insider_hip_handle {
     int *lev = nullptr, *lvl_off_d = nullptr, *members_all = nullptr, *lvl_ptr_all = nullptr, *lvl_count_all = nullptr;
     std::vector<CovTables> cov;
     CovTables cont;                // chunk tables shared by every continuous column
+    // merged row update with continuous covariates (m <= 4, real-valued counts ColFacArgs::zt): column k is a ONE-level
+    // covariate whose membership weights are z_rk — its (gene, weight) list carries sum_{r in H(j)} z_rk^2, its pair "counts"
+    // sum_{r in l} z_rk per categorical level and (Z'Z)[k][k'] per other column, its |l| = sum_r z_rk^2
+    std::vector<CovTables> contm;
+    double *cont_cnt = nullptr;    // [m] sum_r z_rk^2
+    bool cont_merged = false;
     int *ident_members = nullptr;  // 0..n-1
     int max_chunks = 0, max_L = 0;
     double *S = nullptr, *yy_train = nullptr, *yy_all = nullptr;
@@ -153,6 +161,7 @@ struct insider_hip_handle {
     int col_factored = 1;             // option: factored column statistics (insider_col_factored.hpp): 0 list kernel, 1 cost model, 2 look-up form, 3 pair-count form
     uint8_t *cf_cnt = nullptr;        // dense pair counts of every gene (pair-count form), static per data set
     float *cf_hn = nullptr;           // 1/2 held-out count per (gene, level) in the pair-count kernel's order (ColFacArgs::hn)
+    double *cf_zt = nullptr;          // real-valued counts of the continuous covariates in the same order (ColFacArgs::zt), m <= 4
     bool cf_pair_ok = false;
     int cf_pos[CF_MAXC] = {0};        // position of covariate i in cf's order (decreasing level count)
     int row_counts = 1;               // option: k_gene_u from the dense pair counts when they exist
@@ -355,7 +364,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
         if ((rc = dmalloc(&h->U, (size_t)h->p * LP))) return rc;
         if ((rc = dmalloc(&h->Ylvl, (size_t)std::max(h->max_L, 1) * KP))) return rc;
         if ((rc = dmalloc(&h->wpart, (size_t)std::max(h->max_items, 1) * STAT))) return rc;
-        if ((rc = dmalloc(&h->lvl_sum_all, (size_t)std::max(h->SLcat, 1) * (STAT + 2 * KP + 2)))) return rc;
+        if ((rc = dmalloc(&h->lvl_sum_all, (size_t)std::max(h->SL, 1) * (STAT + 2 * KP + 2)))) return rc;
         if ((rc = dmalloc(&h->gram_part2, (size_t)std::max(h->gram_blocks_p, h->gram_blocks_n) * KP * KP))) return rc;
         if ((rc = dmalloc(&h->sc_part2, (size_t)h->sc_blocks * h->SL * KP))) return rc;
         if ((rc = dmalloc(&h->Vlev, (size_t)h->p * h->SLP))) return rc;
@@ -580,7 +589,8 @@ int launch_gene_order(insider_hip_handle *h, const int *sweeps, int reset, int f
 // (model 14.5k vs 48k cycles) and 2.44 vs 0.66 ms (72k vs 24k).
 int col_stats_path(const insider_hip_handle *h)
 {
-    if (!(h->merged && h->col_factored && h->m == 0 && h->c <= CF_MAXC)) return 0;
+    if (!(h->merged && h->col_factored && h->c <= CF_MAXC)) return 0;
+    if (h->m > 0) return (h->cf_pair_ok && h->cf_zt) ? 2 : 0;   // continuous covariates: the pair-count form with real-valued counts, or the lists
     const bool lookup_fits =
         ((size_t)(h->cf.tab_rows + 1) * h->KP + 4 * 16 * 17) * sizeof(double) + (size_t)4 * CF_CAP * 2 <= 64 * 1024;
     if (h->col_factored == 3 && h->cf_pair_ok) return 2;                   // forced
@@ -609,7 +619,8 @@ int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipSt
     NB_DISPATCH(h->NB, {
         (void)WPB_;
         const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
-        hipLaunchKernelGGL((k_col_paircnt<NB_, 4>), dim3(blocks), dim3(256), lds, st, a);
+        if (a.zt) hipLaunchKernelGGL((k_col_paircnt<NB_, 4, true>), dim3(blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_col_paircnt<NB_, 4, false>), dim3(blocks), dim3(256), lds, st, a);
     });
     KCHECK();
     return INSIDER_OK;
@@ -655,6 +666,7 @@ int launch_col_stats(insider_hip_handle *h, bool timed, bool split = false)
         if (col_stats_path(h) == 2) {
             a.cnt = h->cf_cnt;
             a.hn = h->cf_hn;
+            a.zt = h->cf_zt;
             if (split) {
                 // the long branch starts here: everything the main stream has produced so far (row factors, R'R, Qheld)
                 // plus what the side stream prepares for the solve (launch order, sweep-order table, Qfull)
@@ -929,8 +941,8 @@ int launch_test_sse(insider_hip_handle *h, int masked, bool timed)
 // c3: 0.55 vs 1.4 ms (model 0.45 vs 1.38); at c5 (4 covariates): 1.37 vs 0.85 ms (model 1.24 vs 0.84).
 bool use_merged(const insider_hip_handle *h, int masked)
 {
-    if (!(masked && h->merged && h->row_merged && h->m == 0)) return false;
-    if (h->row_merged == 2) return true;   // forced
+    if (!(masked && h->merged && h->row_merged && (h->m == 0 || h->cont_merged))) return false;
+    if (h->row_merged == 2 || h->m > 0) return true;   // forced / continuous covariates: the per-sample pass is the slow alternative
     const int NB = h->NB ? h->NB : 2;
     const double mf = (NB * (NB + 1) / 2) * 16.0 / (1024.0 * 2100.0);   // us per rank-one group entry on the whole GPU
     const double E = (double)h->row_entries, pscale = (double)h->p / 5.0e4;
@@ -991,10 +1003,10 @@ int do_allreduce(insider_hip_handle *h, double *buf, int64_t count)
 }
 
 // level records' Gram part of covariate i: sum_j n_jl c_j c_j' for every level -> rec[l][0 .. STAT)
-int launch_level_gram(insider_hip_handle *h, int i, hipStream_t st, double *rec)
+int launch_level_gram(insider_hip_handle *h, int i, hipStream_t st, double *rec, const CovTables *cont_ct = nullptr)
 {
-    const CovTables &ct = h->cov[i];
-    const WgPlan w = wgemm_plan(h, i, h->K);
+    const CovTables &ct = cont_ct ? *cont_ct : h->cov[i];
+    const WgPlan w = cont_ct ? WgPlan() : wgemm_plan(h, i, h->K);
     if (w.use) {
         const int stat_len = h->NB * (h->NB + 1) / 2 * 256, plen = stat_len + 2 * h->KP + 2;
         const float *hn = h->cf_hn + h->cf.hn_off[h->cf_pos[i]];
@@ -1037,6 +1049,12 @@ int launch_wsyrk_side(insider_hip_handle *h)
     // The weighted SYRK of the first covariate is the longest kernel of the row phase (MFMA-bound on its (level, gene)
     // pairs) and the first thing the main chain waits for: it starts at once.  C'C and (S^train C') (launch_row_prep) run on
     // a third stream: they are first read by k_level_reduce, which waits for ev_prep.
+    // Who is dispatched first decides the phase's length (round 4): when the main chain's k_gene_u (12500 blocks) reaches the
+    // CUs before the level Gram GEMM of covariate 0 (255 blocks, one wave per SIMD), the GEMM's blocks land unevenly between
+    // them and it takes 220 us instead of 140 — 590 against 460 us for the phase, the mode chosen by how the queues happen to
+    // wake up after the solve.  So k_gene_u waits for this event, recorded on the GEMM's stream directly in front of it: its
+    // queue goes on to dispatch the GEMM at once, the main stream's wake-up comes a few microseconds later (and behind V).
+    HIPCHECK(hipEventRecord(h->ev_head, h->side2));
     HIPCHECK(hipStreamWaitEvent(h->side3, h->ev_c_ready, 0));
     if (int rp = launch_gram(h, h->C, h->p, h->CCt, h->side3, h->gram_part2)) return rp;
     if (int rp = launch_mm_reduce_kp(h, h->Strain, h->SLP, h->C, (int)h->p, h->SL, h->sc_part2, h->SC, h->side3)) return rp;
@@ -1045,6 +1063,11 @@ int launch_wsyrk_side(insider_hip_handle *h)
         const int plen = h->NB * (h->NB + 1) / 2 * 256 + 2 * h->KP + 2;
         if (int rg = launch_level_gram(h, i, h->side2, h->lvl_sum_all + (size_t)h->lvl_off[i] * plen)) return rg;
         HIPCHECK(hipEventRecord(h->ev_w[i], h->side2));
+    }
+    for (int k = 0; k < (h->cont_merged ? h->m : 0); ++k) {   // continuous columns: one-level covariates with real-valued weights
+        const int plen = h->NB * (h->NB + 1) / 2 * 256 + 2 * h->KP + 2;
+        if (int rg = launch_level_gram(h, 0, h->side2, h->lvl_sum_all + (size_t)(h->SLcat + k) * plen, &h->contm[k])) return rg;
+        HIPCHECK(hipEventRecord(h->ev_w[h->c + k], h->side2));
     }
     h->w_ready = true;
     return INSIDER_OK;
@@ -1084,15 +1107,45 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
     ra.SC = h->SC;
     ra.sc_off = row0;
     ra.eq = h->eq;
-    if (!cont && use_merged(h, masked)) {
+    if (cont && use_merged(h, masked)) {
+        // merged update of continuous column cont_col (optimize_continuous_v2, src/optimize.cpp:76-137): the one-level covariate
+        // with real-valued membership weights z_r — u_j from the real-valued count table, Y = U'C, the level record's Gram sum
+        // from the (gene, sum z^2) list, sum_r z_r s_r from the real-valued pair counts; then the reference's cyclic scalar
+        // passes on (H, b) (k_cont_cd) as on the per-sample path
+        const int KP = h->KP;
+        const CovTables &cm = h->contm[cont_col];
+        ColFacArgs ca = h->cf;
+        ca.zt = h->cf_zt;
+        hipLaunchKernelGGL((k_gene_uc<4>), dim3(cdiv(h->p, 4)), dim3(256), 0, h->stream, ca, cont_col, (const double *)h->Vlev, h->SLP,
+                           h->U);
+        KCHECK();
+        int ypart_n = 0;
+        if (int rcy = launch_mm_reduce_kp(h, h->U, 2, h->C, (int)h->p, 1, h->sc_part, nullptr, nullptr, &ypart_n)) return rcy;
+        if (h->w_ready) {
+            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[h->c + cont_col], 0));
+            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
+        }
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            constexpr int STAT_ = Geo<NB_>::STAT, PLEN = STAT_ + 2 * Geo<NB_>::KP + 2;
+            double *rec = h->w_ready ? h->lvl_sum_all + (size_t)row0 * PLEN : h->lvl_sum;
+            if (!h->w_ready)
+                if (int rg = launch_level_gram(h, 0, h->stream, rec, &cm)) return rg;
+            hipLaunchKernelGGL((k_level_merged<NB_>), dim3(1), dim3(256), 0, h->stream, (const double *)rec, (const double *)h->sc_part,
+                               ypart_n, (const double *)cm.paircnt, h->SL, (const double *)h->Astack, (const int *)h->one_count,
+                               (const double *)h->CCt, (const double *)(h->SC + (size_t)row0 * KP), 1, h->K, lambda1, 0, h->eq,
+                               h->Astack + (size_t)row0 * KP, h->failflag, (const double *)(h->cont_cnt + cont_col));
+        });
+    } else if (!cont && use_merged(h, masked)) {
         // merged update: one weighted rank-one term per (level, gene) pair, one look-up per held-out entry
         const int L = ct.L, LP = (int)round_up(L, 2), KP = h->KP;
-        if (h->cf_pair_ok && h->row_counts && h->c <= CF_MAXC) {   // u from the dense pair counts (insider_col_factored.hpp)
+        const size_t gu_lds = (size_t)4 * (h->SL + LP + GU_BATCH * WAVE) * sizeof(double);
+        if (h->cf_pair_ok && (h->row_counts || h->m > 0) && h->c <= CF_MAXC && gu_lds <= 64 * 1024) {   // u from the dense pair counts (insider_col_factored.hpp)
             ColFacArgs ca = h->cf;
             ca.cnt = h->cf_cnt;
-            hipLaunchKernelGGL((k_gene_u_cnt<4>), dim3(cdiv(h->p, 4)), dim3(256),
-                               (size_t)4 * (h->SLcat + LP + WAVE) * sizeof(double), h->stream, ca, h->cf_pos[i], LP,
-                               (const double *)h->Vlev, h->SLP, h->SLcat, h->U);
+            ca.zt = h->m > 0 ? h->cf_zt : nullptr;   // (+ the continuous covariates' term from the real-valued counts)
+            hipLaunchKernelGGL((k_gene_u_cnt<4>), dim3(cdiv(h->p, 4)), dim3(256), gu_lds, h->stream, ca, h->cf_pos[i], LP,
+                               (const double *)h->Vlev, h->SLP, h->SL, h->U);
         } else {
             hipLaunchKernelGGL((k_gene_u<4>), dim3(cdiv(h->p, 4)), dim3(256), (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double),
                                h->stream, (const uint32_t *)ct.grp, (const uint16_t *)ct.slev,
@@ -1120,13 +1173,13 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
             fused_solve = h->world <= 1 && !h->force_allreduce && h->row_fused && NB_ <= 2;
             if (h->row_fused)
                 hipLaunchKernelGGL((k_level_merged<NB_>), dim3(L), dim3(256), 0, h->stream, (const double *)rec,
-                                   (const double *)(ypart_n ? h->sc_part : h->Ylvl), ypart_n, (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
+                                   (const double *)(ypart_n ? h->sc_part : h->Ylvl), ypart_n, (const double *)ct.paircnt, h->SL, (const double *)h->Astack,
                                    (const int *)(h->lvl_count_all + h->lvl_off[i]), (const double *)h->CCt,
                                    (const double *)(h->SC + (size_t)row0 * KP), L, h->K, lambda1, fused_solve ? 1 : 0, h->eq,
                                    h->Astack + (size_t)row0 * KP, h->failflag);
             else {
                 hipLaunchKernelGGL(k_level_pack, dim3(L), dim3(256), 0, h->stream, (const double *)h->Ylvl,
-                                   (const double *)ct.paircnt, h->SLcat, (const double *)h->Astack,
+                                   (const double *)ct.paircnt, h->SL, (const double *)h->Astack,
                                    (const int *)(h->lvl_count_all + h->lvl_off[i]), L, h->K, KP, STAT_, rec);
                 ra.part = rec;
                 hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(L), dim3(64), 0, h->stream, ra);
@@ -1345,9 +1398,10 @@ hipError_t make_streams(insider_hip_handle *h)
     MS(hipEventCreateWithFlags(&h->ev_long_done, hipEventDisableTiming));
     MS(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
     MS(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_head, hipEventDisableTiming));
     MS(hipEventCreateWithFlags(&h->ev_a_ready, hipEventDisableTiming));
     MS(hipEventCreateWithFlags(&h->ev_qfull, hipEventDisableTiming));
-    h->ev_w.assign(h->c > 0 ? h->c : 1, nullptr);
+    h->ev_w.assign((h->c > 0 ? h->c : 1) + h->m, nullptr);
     for (auto &ev : h->ev_w) MS(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     MS(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
     MS(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
@@ -1359,7 +1413,7 @@ hipError_t make_streams(insider_hip_handle *h)
 void destroy_streams(insider_hip_handle *h)
 {
     for (hipStream_t *st : {&h->side, &h->side2, &h->side3, &h->lng}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
-    for (hipEvent_t *ev : {&h->ev_long_go, &h->ev_long_done, &h->ev_prep, &h->ev_c_ready, &h->ev_a_ready, &h->ev_qfull, &h->ev_cd_done,
+    for (hipEvent_t *ev : {&h->ev_long_go, &h->ev_long_done, &h->ev_prep, &h->ev_c_ready, &h->ev_head, &h->ev_a_ready, &h->ev_qfull, &h->ev_cd_done,
                            &h->ev_side_done, &h->ev_tab}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
     for (auto ev : h->ev_w) if (ev) (void)hipEventDestroy(ev);
     h->ev_w.clear();
@@ -1388,6 +1442,14 @@ void free_data_set(insider_hip_handle *h)
     if (h->Sheld) (void)hipFree(h->Sheld);
     if (h->cf_cnt) (void)hipFree(h->cf_cnt);
     if (h->cf_hn) (void)hipFree(h->cf_hn);
+    if (h->cf_zt) (void)hipFree(h->cf_zt);
+    if (h->cont_cnt) (void)hipFree(h->cont_cnt);
+    for (size_t k = 0; k < h->contm.size(); ++k) {
+        CovTables &ct = h->contm[k];
+        for (void *q : {(void *)(k == 0 ? ct.wl_idx : nullptr), (void *)ct.wl_w, (void *)(k == 0 ? ct.item_begin : nullptr),
+                        (void *)(k == 0 ? ct.item_end : nullptr), (void *)(k == 0 ? ct.lvl_item_ptr : nullptr), (void *)ct.paircnt})
+            if (q) (void)hipFree(q);   // (the index list and the work items are shared by the columns: freed with column 0)
+    }
 }
 }  // namespace
 
@@ -1418,7 +1480,7 @@ int insider_hip_clone(insider_hip_handle *src, insider_hip_handle **out)
     insider_hip_handle *h = new insider_hip_handle(*src);   // every data-set field and option; the rest is reset below
     forget_workspace(h);                                    // (the copied pointers are the source's buffers)
     h->stream = h->side = h->side2 = h->side3 = h->lng = nullptr;
-    h->ev_long_go = h->ev_long_done = h->ev_prep = h->ev_c_ready = h->ev_a_ready = h->ev_qfull = nullptr;
+    h->ev_long_go = h->ev_long_done = h->ev_prep = h->ev_c_ready = h->ev_head = h->ev_a_ready = h->ev_qfull = nullptr;
     h->ev_cd_done = h->ev_side_done = h->ev_tab = nullptr;
     h->ev_w.clear();
     for (auto *v : {&h->ev_col, &h->ev_row, &h->ev_cd, &h->ev_test}) v->clear();
@@ -1613,7 +1675,7 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
         hipLaunchKernelGGL(k_level_sums, dim3(cdiv(p * h->SLcat, 256)), dim3(256), 0, h->stream, (const double *)h->X,
                            (const uint8_t *)nullptr, h->ldn, (int)p, (const int *)h->members_all,
                            (const int *)h->lvl_ptr_all, (const int *)h->lvl_off_d, c, (int)n, h->SLcat, h->SLP, h->S);
-        if (m == 0) {   // train-only sums for the merged masked row update (categorical covariates only)
+        {   // train-only sums for the merged masked row update / the factored column statistics (the categorical columns)
             CR(dmalloc(&h->Strain, (size_t)p * h->SLP));
             CH(hipMemsetAsync(h->Strain, 0, (size_t)p * h->SLP * sizeof(double), h->stream));
             hipLaunchKernelGGL(k_level_sums, dim3(cdiv(p * h->SLcat, 256)), dim3(256), 0, h->stream, (const double *)h->X,
@@ -1672,7 +1734,8 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
     // ---- merged masked row update: per covariate, the genes' held-out samples grouped by level, the (gene, count)
     // lists of every level and the level-pair sample counts (insider_row_merged.hpp) -------------------------------------
     // (k_gene_u keeps a gene's SLcat look-up values per wave in LDS: beyond ~1500 stacked levels the per-sample path stays)
-    if (m == 0 && (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double) <= 64 * 1024) {
+    // (with continuous covariates, m <= 4: the same tables serve the pair-count column statistics, ColFacArgs::zt)
+    if (m <= 4 && (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double) <= 64 * 1024) {
         constexpr uint32_t SEG = 1024;   // list entries per weighted-SYRK work item (multiple of LIST_ALIGN)
         std::vector<int> lev0((size_t)c * n);
         CH(hipMemcpy(lev0.data(), h->lev, lev0.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -1728,11 +1791,13 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
             CH(hipMemcpy(ct.item_end, ie.data(), ie.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             CH(hipMemcpy(ct.lvl_item_ptr, lip.data(), lip.size() * sizeof(int), hipMemcpyHostToDevice));
             // samples per (level of covariate i, stacked level of another covariate): sum_{r in l} s_r = paircnt A
-            std::vector<double> pc((size_t)L * h->SLcat, 0.0);
+            // (+ m columns sum_{r in l} z_rk: a continuous column is a stacked "level" with real-valued counts)
+            std::vector<double> pc((size_t)L * h->SL, 0.0);
             for (int64_t r = 0; r < n; ++r) {
                 const int l = lev0[(size_t)i * n + r];
                 for (int q = 0; q < c; ++q)
-                    if (q != i) pc[(size_t)l * h->SLcat + h->lvl_off[q] + lev0[(size_t)q * n + r]] += 1.0;
+                    if (q != i) pc[(size_t)l * h->SL + h->lvl_off[q] + lev0[(size_t)q * n + r]] += 1.0;
+                for (int k = 0; k < m; ++k) pc[(size_t)l * h->SL + h->SLcat + k] += ctns[(size_t)k * n + r];
             }
             CR(dmalloc(&ct.paircnt, pc.size()));
             CH(hipMemcpy(ct.paircnt, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1806,6 +1871,94 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
                 }
                 h->cf_pair_ok = fits;
             }
+            cf.zt = nullptr;
+            cf.m = m;
+            cf.SLcat = h->SLcat;
+            for (int t = 0; t < c; ++t) cf.pos_cov[t] = ord[t];
+            if (m > 0 && h->cf_pair_ok) {
+                // continuous covariates on the pair-count form: one more position (the m columns as pseudo-levels, no count
+                // bytes, 1/2 n = 0: sixteen more zero floats per gene would do, the block reads what follows its offset ->
+                // its own zero region) and the real-valued count table
+                cf.L[c] = m;
+                cf.off[c] = h->SLcat;
+                cf.nlater[c] = 0;
+                cf.cnt_off[c] = 0;
+                int zoff = 0;
+                for (int t = 0; t < c; ++t) { cf.zt_off[t] = zoff; zoff += ((cf.L[t] + 15) / 16) * 64; }
+                cf.zt_off[c] = zoff;
+                cf.zt_stride = zoff + 64;
+                // 1/2 n of position c: a zero region behind the table (rebuilt with the longer stride)
+                (void)hipFree(h->cf_hn);
+                h->cf_hn = nullptr;
+                cf.hn_off[c] = cf.hn_stride;
+                cf.hn_stride += 16;
+                CR(dmalloc(&h->cf_hn, (size_t)(p + 4) * cf.hn_stride));
+                CH(hipMemsetAsync(h->cf_hn, 0, (size_t)(p + 4) * cf.hn_stride * sizeof(float), h->stream));
+                hipLaunchKernelGGL(k_half_counts, dim3((unsigned)cdiv((int64_t)p * cf.hn_stride, 256)), dim3(256), 0, h->stream, cf,
+                                   h->cf_hn);
+                CH(hipGetLastError());
+                CR(dmalloc(&h->cf_zt, (size_t)p * cf.zt_stride));
+                CH(hipMemsetAsync(h->cf_zt, 0, (size_t)p * cf.zt_stride * sizeof(double), h->stream));
+                // (Sheld's continuous columns: sum over the held-out entries of x z, next to S - S^train of the categorical ones)
+                hipLaunchKernelGGL(k_zt_build, dim3(cdiv(p, 4)), dim3(256), 0, h->stream, cf, (const uint32_t *)h->col_ptr,
+                                   (const int *)h->col_idx, (const double *)h->col_val, (const int *)h->lev, (const double *)h->Zc,
+                                   (int)n, h->cf_zt, h->Sheld, h->SLP, (const double *)h->S, h->Strain);
+                CH(hipGetLastError());
+                CH(hipStreamSynchronize(h->stream));
+                // ---- the continuous columns as one-level covariates of the merged row update ----
+                h->contm.assign(m, CovTables());
+                const size_t plen_l = (size_t)round_up(p, LIST_ALIGN);
+                std::vector<int> widx(plen_l, LIST_PAD);
+                for (int64_t j = 0; j < p; ++j) widx[j] = (int)j;
+                std::vector<uint32_t> ib, ie;
+                for (size_t b = 0; b < plen_l; b += SEG) { ib.push_back((uint32_t)b); ie.push_back((uint32_t)std::min(b + SEG, plen_l)); }
+                const int lip[2] = {0, (int)ib.size()};
+                int *d_idx = nullptr, *d_lip = nullptr;
+                uint32_t *d_ib = nullptr, *d_ie = nullptr;
+                CR(dmalloc(&d_idx, plen_l + LIST_BLOCK));
+                CR(dmalloc(&d_ib, ib.size() + 1));
+                CR(dmalloc(&d_ie, ie.size() + 1));
+                CR(dmalloc(&d_lip, 2));
+                CH(hipMemcpy(d_idx, widx.data(), plen_l * sizeof(int), hipMemcpyHostToDevice));
+                CH(hipMemcpy(d_ib, ib.data(), ib.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                CH(hipMemcpy(d_ie, ie.data(), ie.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                CH(hipMemcpy(d_lip, lip, sizeof(lip), hipMemcpyHostToDevice));
+                h->max_items = std::max(h->max_items, (int)ib.size());
+                std::vector<double> zz((size_t)m * m, 0.0);
+                for (int k = 0; k < m; ++k)
+                    for (int k2 = 0; k2 < m; ++k2) {
+                        double acc = 0.0;
+                        for (int64_t r = 0; r < n; ++r) acc += ctns[(size_t)k * n + r] * ctns[(size_t)k2 * n + r];
+                        zz[(size_t)k * m + k2] = acc;
+                    }
+                std::vector<double> cc(m);
+                for (int k = 0; k < m; ++k) {
+                    CovTables &ct = h->contm[k];
+                    ct.L = 1;
+                    ct.wl_idx = d_idx;
+                    ct.item_begin = d_ib;
+                    ct.item_end = d_ie;
+                    ct.lvl_item_ptr = d_lip;
+                    ct.nitems = (int)ib.size();
+                    ct.npairs = p;
+                    CR(dmalloc(&ct.wl_w, plen_l + LIST_BLOCK));
+                    CH(hipMemsetAsync(ct.wl_w, 0, (plen_l + LIST_BLOCK) * sizeof(double), h->stream));
+                    hipLaunchKernelGGL(k_cont_weights, dim3(cdiv(p, 256)), dim3(256), 0, h->stream, (const double *)h->cf_zt, cf.zt_stride,
+                                       cf.zt_off[c], k, (int)p, ct.wl_w);
+                    CH(hipGetLastError());
+                    std::vector<double> pc((size_t)h->SL, 0.0);
+                    for (int64_t r = 0; r < n; ++r)
+                        for (int q = 0; q < c; ++q) pc[h->lvl_off[q] + lev0[(size_t)q * n + r]] += ctns[(size_t)k * n + r];
+                    for (int k2 = 0; k2 < m; ++k2) pc[h->SLcat + k2] = k2 == k ? 0.0 : zz[(size_t)k * m + k2];
+                    CR(dmalloc(&ct.paircnt, pc.size()));
+                    CH(hipMemcpy(ct.paircnt, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice));
+                    cc[k] = zz[(size_t)k * m + k];
+                }
+                CR(dmalloc(&h->cont_cnt, (size_t)m));
+                CH(hipMemcpy(h->cont_cnt, cc.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+                CH(hipStreamSynchronize(h->stream));
+                h->cont_merged = true;
+            }
         }
     }
     // the transposed copies were only needed to build the row-side lists
@@ -1876,6 +2029,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
     else if (s == "row_gemm_waves") { h->wg_waves = std::max(64, (int)value); h->K = 0; }   // (re-plans the workspace)
     else if (s == "row_gemm") h->row_gemm = (int)value;       // 1 (default) = k_wgemm for covariates with >= 49 levels, 0 = k_wsyrk everywhere
+    else if (s == "row_head") h->row_head = (int)value;       // 1 (default) = the main chain's k_gene_u is dispatched behind the level Gram GEMM (launch_wsyrk_side)
     else if (s == "row_fused") h->row_fused = (int)value;     // 1 (default) = k_level_merged (one launch per covariate), 0 = k_level_pack / k_level_reduce / k_level_solve
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
@@ -1950,20 +2104,26 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
         // V = C A' of the covariates 1 .. c-1: what covariate 0's update reads.  Covariate 0's own columns are first read by
         // covariate 1's update, after they have been recomputed from the updated factors (below): not formed here
 #ifdef INSIDER_V_ALL   // (A/B builds: every column, as before round 3)
-        if (use_merged(h, masked)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
+        if (use_merged(h, masked)) if ((rc = launch_gene_v(h, 0, h->SL))) return rc;
 #else
-        if (use_merged(h, masked)) if ((rc = launch_gene_v(h, h->c > 1 ? h->lvl_off[1] : h->SLcat, h->SLcat))) return rc;
+        // (with continuous covariates on the merged form: their columns of V too — s_r carries A_c' z_r)
+        if (use_merged(h, masked)) if ((rc = launch_gene_v(h, h->c > 1 ? h->lvl_off[1] : h->SLcat, h->SL))) return rc;
 #endif
+        if (use_merged(h, masked) && h->row_head) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_head, 0));   // launch_wsyrk_side
+        const bool cont_follow = inc_continuous && h->m > 0;
         for (int i = 0; i < h->c; ++i) {
-            const bool need_R = !use_merged(h, masked) || i + 1 == h->c;
+            const bool need_R = !use_merged(h, masked) || (i + 1 == h->c && !cont_follow);
             if ((rc = row_update(h, i, -1, masked, lambda1, need_R))) return rc;                // :339
-            if (use_merged(h, masked) && i + 1 < h->c)
+            if (use_merged(h, masked) && (i + 1 < h->c || cont_follow))   // (the continuous columns read every categorical column of V)
                 if ((rc = launch_gene_v(h, h->lvl_off[i], h->lvl_off[i + 1]))) return rc;
         }
+        if (cont_follow)
+            for (int j = 0; j < h->m; ++j) {
+                if ((rc = row_update(h, 0, j, masked, lambda1, !use_merged(h, masked) || j + 1 == h->m))) return rc;   // :340-351
+                if (use_merged(h, masked) && j + 1 < h->m)
+                    if ((rc = launch_gene_v(h, h->SLcat + j, h->SLcat + j + 1))) return rc;
+            }
         h->w_ready = false;
-        if (inc_continuous)
-            for (int j = 0; j < h->m; ++j)
-                if ((rc = row_update(h, 0, j, masked, lambda1))) return rc;                     // :340-351
         // ---- column step (:365-378) -------------------------------------------------------------------------------
         if ((rc = phase_R(h, true, true))) return rc;
         const int checkpoint = iter % 10 == 0;
@@ -2142,7 +2302,7 @@ int insider_hip_optimize_row(insider_hip_handle *h, double *const *A, const doub
     if ((rc = launch_row_prep(h, tuning))) return rc;
     if (tuning == 1 && !use_merged(h, tuning)) if ((rc = launch_row_stats(h, false))) return rc;
     if ((rc = launch_build_R(h))) return rc;
-    if (use_merged(h, tuning)) if ((rc = launch_gene_v(h, 0, h->SLcat))) return rc;
+    if (use_merged(h, tuning)) if ((rc = launch_gene_v(h, 0, h->SL))) return rc;
     if (cov < h->c) rc = row_update(h, cov, -1, tuning, lambda);
     else rc = row_update(h, 0, cov - h->c, tuning, lambda);
     if (rc) return rc;
@@ -2416,7 +2576,9 @@ int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out)
             for (int t = 0; t < h->cf.c; ++t) {
                 v += std::ceil(h->cf.L[t] / 4.0) * NB * NB;                                           // M += A' P
                 if (path == 2 && h->cf.nlater[t] > 0) v += std::ceil(h->cf.L[t] / 16.0) * h->cf.nsteps * NB;   // P = N_j Tab
+                if (path == 2 && h->m > 0) v += std::ceil(h->cf.L[t] / 16.0) * NB;                            // + real-valued counts
             }
+        if (path == 2 && h->m > 0) v += std::ceil(h->m / 4.0) * NB * NB + NB;                                 // the continuous position
         *out = v;
     } else return fail(INSIDER_ERR_ARG, "unknown info key " + s);
     return INSIDER_OK;

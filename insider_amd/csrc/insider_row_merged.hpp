@@ -432,7 +432,8 @@ __global__ void __launch_bounds__(256) k_level_merged(const double *__restrict__
                                                       const double *__restrict__ Astack, const int *__restrict__ lvl_count,
                                                       const double *__restrict__ CCt, const double *__restrict__ SC /*rows of this covariate*/,
                                                       int L, int K, double lambda, int do_solve, double *__restrict__ eq,
-                                                      double *__restrict__ Arows /*L x KP*/, int *__restrict__ fail)
+                                                      double *__restrict__ Arows /*L x KP*/, int *__restrict__ fail,
+                                                      const double *__restrict__ cnt_real = nullptr /*[L]: real-valued |l| (sum_r z_r^2 of a continuous column) instead of lvl_count*/)
 {
     constexpr int KP = Geo<NB>::KP, NBLK = Geo<NB>::NBLK, STAT = Geo<NB>::STAT;
     __shared__ double red[4][64];
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(256) k_level_merged(const double *__restrict__
     if (g != 0) return;
     const bool valid = lane < K;
     const int sub = lane >> 4, c16 = lane & 15;
-    const double cnt = (double)lvl_count[l];
+    const double cnt = cnt_real ? cnt_real[l] : (double)lvl_count[l];
     double v = 0.0;
     if (valid) {
         if (ypart_n > 0) {
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(256) k_level_merged(const double *__restrict__
         eql[KP * KP + lane] = yv;
     }
     if constexpr (NB <= 2) {
-        if (!do_solve || lvl_count[l] == 0) return;   // level without samples: the reference never visits it (:147)
+        if (!do_solve || cnt_real || lvl_count[l] == 0) return;   // level without samples: the reference never visits it (:147)
         wave_sync();
         double b = lane < KP ? yv : 0.0;
         double row[KP];

@@ -114,10 +114,13 @@ def run_hip(case, extra=None, iters=None, want_sweeps=False):
     return (got, err, sw) if want_sweeps else (got, err)
 
 
-def run_oracle(case, iters=None, want_sweeps=False):
+def run_oracle(case, iters=None, want_sweeps=False, cd_form=0):
+    """cd_form = 0: the parity oracle (the reference's residual-form CD).  cd_form = 1: the SAME oracle with covariance-form
+    sweeps (oracle_set_cd_form; a diagnostic, never the checker): what separates the formulation's rounding from a kernel's."""
     from oracle import c_oracle   # test infrastructure: the checker
     w, A, C, Z = inputs(case)
     sink = c_oracle.set_sweep_sink(w.p) if want_sweeps else None
+    c_oracle.set_cd_form(cd_form)
     try:
         ref = c_oracle.optimize(w.X, w.levels, w.n_levels, A, C, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=w.tuning,
                                 max_iter=case["iters"] if iters is None else iters, seed=case["seed"], max_sweeps=300,
@@ -126,6 +129,7 @@ def run_oracle(case, iters=None, want_sweeps=False):
     except Exception as e:
         ref, rerr = None, e
     finally:
+        c_oracle.set_cd_form(0)
         if want_sweeps:
             c_oracle.set_sweep_sink(None)
     return (ref, rerr, None if sink is None else sink.copy()) if want_sweeps else (ref, rerr)

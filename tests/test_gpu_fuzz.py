@@ -27,10 +27,16 @@ def test_repeated_calls_are_bitwise_reproducible_and_leak_free():
 
 # ---- the frozen outliers of the long randomised sweeps ---------------------------------------------------
 # tests/golden/fuzz_outliers.json: cases (explicit parameters, tests/fuzz_parity.py:draw_case) whose HIP fit ends OUTSIDE the
-# suite's base tolerances against the oracle (factors 1e-7, trajectory 1e-8).  The claim these tests make executable: the
-# deviation is not a kernel's — every kernel form of the library produces the same fit — but a stopping decision at rounding
-# level (|loss change| <= tol, src/coordinate_descent.cpp:114) that falls differently in the oracle's residual-form loss
-# difference and then amplifies through the following outer iterations.
+# suite's base tolerances against the oracle (factors 1e-7, trajectory 1e-8); found by a 7000-case sweep with FUZZ_TIGHT=1
+# (25 such cases: all with sub_tol <= 1e-8, most with K close to or above the number of training samples of a gene).  The claim
+# these tests make executable: the deviation is the FORMULATION's, not a kernel's.  The library runs coordinate descent in
+# covariance form (gradient = Xty - XtX beta), the reference and the parity oracle on the residual vector; on an
+# ill-conditioned subproblem the two round differently (cancellation in Xty - XtX beta), sometimes enough to flip a stopping
+# decision (|loss change| <= tol at rounding level, src/coordinate_descent.cpp:114), and the difference feeds through the
+# following outer iterations.  Executable form: (i) every kernel form of the library gives the same fit; (ii) the library
+# agrees with the ORACLE RUN IN COVARIANCE FORM (same C code, oracle_set_cd_form(1)) within the base tolerances, or their
+# per-gene sweep counts show a stopping decision that differs; (iii) the two forms of the oracle differ from EACH OTHER — on
+# the CPU alone — by as much as the library differs from the parity oracle; (iv) the deviation stays within the recorded one.
 def _outliers():
     import json
     path = os.path.join(HERE, "golden", "fuzz_outliers.json")
@@ -49,6 +55,7 @@ def test_fuzz_outlier_is_not_a_kernels(idx):
     base, err = fz.run_hip(case)
     assert base is not None, err
     dev = fz.errors(base, ref)
+    assert base["iters"] == ref["iters"]
     # (i) every kernel form of the library gives the same fit: per-entry / look-up / pair-count statistics, the three CD
     #     kernels, single- and multi-pass solves agree with each other orders of magnitude more closely than with the oracle
     for form in fz.FORMS[1:]:
@@ -57,26 +64,23 @@ def test_fuzz_outlier_is_not_a_kernels(idx):
         cross = fz.errors(got, base)
         assert max(cross[0], cross[1]) < 1e-9 and cross[2] < 1e-10, (form, cross, dev)
         assert got["iters"] == base["iters"]
-    # (ii) HIP and oracle agree until their stopping decisions first differ: fits of 0, 1, ... outer iterations, per-gene
-    #      sweep counts of the last column step on both sides
-    first = None
+    # (ii) against the oracle in COVARIANCE form: base tolerances, unless a stopping decision differs (per-gene sweep counts of
+    #      the last column step of fits of 0, 1, ... outer iterations)
+    cov, cerr = fz.run_oracle(case, cd_form=1)
+    assert cov is not None, cerr
+    dev_cov = fz.errors(base, cov)
+    flipped = None
     for it in range(case["iters"] + 1):
-        g, _, sw_h = fz.run_hip(case, iters=it, want_sweeps=True)
-        r, _, sw_o = fz.run_oracle(case, iters=it, want_sweeps=True)
-        same = sw_h is not None and sw_o is not None and np.array_equal(sw_h, sw_o)
-        if same:
-            e = fz.errors(g, r)
-            assert max(e[0], e[1]) < 1e-7 and e[2] < 1e-8, (it, e)          # no decision has differed yet: base tolerances hold
-        elif first is None:
-            first = it
-            differ = np.flatnonzero(sw_h != sw_o)
-            assert differ.size <= max(2, sw_o.size // 10), (it, differ.size)  # a few genes, not a systematic difference
-            keep = np.setdiff1d(np.arange(sw_o.size), differ)
-            ck, cr = g["column_factor"][:, keep], r["column_factor"][:, keep]
-            assert np.linalg.norm(ck - cr) / max(np.linalg.norm(cr), 1e-300) < 1e-7  # the other genes' solves still agree
-    assert first is not None, "no stopping decision differs: this case should meet the base tolerances"
-    # (iii) the deviation at the end stays within what the fixture records (x 3: packing-independent, but not bit-stable
-    #       across compilers of the oracle)
+        _, _, sw_h = fz.run_hip(case, iters=it, want_sweeps=True)
+        _, _, sw_o = fz.run_oracle(case, iters=it, want_sweeps=True, cd_form=1)
+        if sw_h is None or sw_o is None or not np.array_equal(sw_h, sw_o):
+            flipped = it
+            break
+    assert flipped is not None or (max(dev_cov[0], dev_cov[1]) < 1e-7 and dev_cov[2] < 1e-8), (dev_cov, dev)
+    # (iii) the oracle's two forms differ from each other, with no GPU involved, by as much as the library from the parity oracle
+    form_gap = fz.errors(dict(row_matrices={f"factor{i}": a for i, a in enumerate(cov["row_matrices"])},
+                              column_factor=cov["column_factor"], traj=cov["traj"]), ref)
+    assert max(form_gap[0], form_gap[1]) > 0.2 * max(dev[0], dev[1]), (form_gap, dev)
+    # (iv) the deviation stays within what the fixture records (x 3: not bit-stable across compilers of the oracle)
     tol = case["tolerated"]
     assert dev[0] <= 3 * tol["row"] and dev[1] <= 3 * tol["col"] and dev[2] <= 3 * tol["traj"], (dev, tol)
-    assert base["iters"] == ref["iters"]
