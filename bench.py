@@ -26,7 +26,7 @@ Prints ONE JSON line on rank 0:
   grid          (--grid) BASELINE config 3 as written: tune() over lambda in {1,3,..,19} x alpha in {.2,.3,.4,.5}
 """
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything initialises the HIP runtime (see insider_amd/_lib.py: concurrent fits)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before anything initialises the HIP runtime (see insider_amd/_lib.py: concurrent fits)
 import argparse
 import hashlib
 import json

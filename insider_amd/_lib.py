@@ -61,7 +61,7 @@ def load():
     # Concurrent fits on one GPU (insider_hip_clone, tune(concurrent=k)) need their streams on DIFFERENT hardware queues: the
     # HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES queues (default 4), and two fits whose main
     # streams share a queue run one after the other.  Read by the runtime when it initialises: set before the first HIP call.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     lib = C.CDLL(LIB_PATH)
     dp, i32p, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
     lib.insider_hip_version.restype = C.c_char_p

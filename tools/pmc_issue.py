@@ -109,7 +109,7 @@ print(open(out + ".csv").read().split("\n\n")[0])
 
 # profiles/issue.json: the sweep and the statistics kernel of this workload, keyed by the hash of the library that ran
 from insider_amd import _build  # noqa: E402
-ipath = os.path.join(ROOT, "profiles", "issue.json")
+ipath = os.environ.get("INSIDER_ISSUE_JSON") or os.path.join(ROOT, "profiles", "issue.json")   # (on the GPU box: under gpurun_out/)
 ij = json.load(open(ipath)) if os.path.exists(ipath) else {}
 sha = _build.library_sha()
 if ij.get("source_sha") != sha:

@@ -20,5 +20,5 @@ for P in "$P1" "$P2" "$P3"; do
   echo "pass $i done"
 done
 cd $R
-python3 tools/pmc_issue.py $WL $OUT/${WL}_pmc_issue $OUT/pmc_issue_${WL}_1 $OUT/pmc_issue_${WL}_2 $OUT/pmc_issue_${WL}_3
+INSIDER_ISSUE_JSON=$OUT/issue.json python3 tools/pmc_issue.py $WL $OUT/${WL}_pmc_issue $OUT/pmc_issue_${WL}_1 $OUT/pmc_issue_${WL}_2 $OUT/pmc_issue_${WL}_3
 echo PMC_ISSUE_DONE
