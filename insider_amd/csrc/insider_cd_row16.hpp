@@ -1,4 +1,8 @@
-// insider_cd_row16.hpp — "row16" elastic-net coordinate descent for K <= 32: four genes per wavefront.
+// insider_cd_row16.hpp — "row16" elastic-net coordinate descent, four genes per wavefront, Gram matrix in LDS: the cross-check
+// of the register-resident kernel for K <= 32 (SLOTS = 1, 2) and, since round 4, THE sweep kernel for 32 < K <= 48 (SLOTS = 3),
+// where the Gram matrix does not fit registers and two waves' blocks still fit a CU's LDS (beyond: k_cd_cols<64, 1>).
+// (Also measured there and dropped: the register kernel's scaled state — soft threshold as the output clamp, increments through a
+// DPP fmac — with the LDS reads issued a step ahead: +4 %; the kernel is bound by its occupancy, two waves per CU, not by the chain.)
 //
 // The sweep loop of strong_coordinate_descent (src/coordinate_descent.cpp:86-114) is a K-step sequential
 // recurrence per gene and, at BASELINE's tolerances, runs for hundreds to thousands of sweeps: it is issue-bound
@@ -33,9 +37,15 @@ __device__ __forceinline__ double row16_max(double v)
     return v;
 }
 
-// LDS doubles per wave: 4 Gram blocks of K*K (zero diagonal, pitch K) + per gene 32 diagonal entries, 32 effective
-// 1/(XtX_kk + l2) (0 = screened out), 32 staging slots
-__host__ __device__ inline int r16_lds_doubles(int K) { return 4 * K * K + 3 * 128; }
+// LDS doubles per wave: 4 Gram blocks of K*K (zero diagonal, pitch K) + per gene NC diagonal entries, NC effective
+// 1/(XtX_kk + l2) (0 = screened out), NC staging slots; NC = 32 up to K = 32, 64 beyond (round 4: SLOTS = 3, 4 for K <= 63)
+__host__ __device__ inline int r16_nc(int K) { return K <= 32 ? 32 : 64; }
+// doubles between the Gram blocks of the wave's four genes: K * K rounded up to 8 mod 32, i.e. the blocks are 64 bytes mod 256
+// apart in LDS.  All genes follow the same coordinate order, so lane i of every row reads the SAME (row, column) of its
+// gene's block in every step: with blocks a multiple of 256 bytes apart (K = 40: 12800) the four reads hit the same banks —
+// SQ_LDS_BANK_CONFLICT was 69 % of the LDS cycles of the K = 40 kernel (round 4)
+__host__ __device__ inline int r16_gstride(int K) { return ((K * K + 23) / 32) * 32 + 8; }
+__host__ __device__ inline int r16_lds_doubles(int K) { return 4 * r16_gstride(K) + 3 * 4 * r16_nc(K); }
 
 template <int SLOTS>
 struct R16State {
@@ -82,13 +92,17 @@ __device__ __forceinline__ void r16_gemv_step(double (&acc)[SLOTS], const double
 #define R16_UNROLL32(F)                                                                                     \
     F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17) F(18)    \
     F(19) F(20) F(21) F(22) F(23) F(24) F(25) F(26) F(27) F(28) F(29) F(30) F(31)
+// positions 32 .. 63 (slots 2 and 3; the steps are constexpr-guarded by `s < SLOTS`, so the two-slot instantiations lose nothing)
+#define R16_UNROLL64(F)                                                                                     \
+    R16_UNROLL32(F) F(32) F(33) F(34) F(35) F(36) F(37) F(38) F(39) F(40) F(41) F(42) F(43) F(44) F(45) F(46) \
+    F(47) F(48) F(49) F(50) F(51) F(52) F(53) F(54) F(55) F(56) F(57) F(58) F(59) F(60) F(61) F(62) F(63)
 
 template <int SLOTS>
 __device__ __forceinline__ void r16_gemv(double (&acc)[SLOTS], const double (&v)[SLOTS], const int (&col)[SLOTS],
                                          const char *L, int K, int pitchB)
 {
 #define R16_G(M) r16_gemv_step<SLOTS, M>(acc, v, col, L, K, pitchB);
-    R16_UNROLL32(R16_G)
+    R16_UNROLL64(R16_G)
 #undef R16_G
 }
 
@@ -121,8 +135,9 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
     const int row = lane >> 4, i = lane & 15;
     const int pitchB = K * 8;
     const char *L = reinterpret_cast<const char *>(lds);
-    const int gbase = row * K * K * 8;                              // byte offset of this gene's Gram block
-    double *GllT = lds + 4 * K * K + row * 32, *invT = GllT + 128, *stage = invT + 128;
+    const int gbase = row * r16_gstride(K) * 8;                     // byte offset of this gene's Gram block
+    const int NC = r16_nc(K);
+    double *GllT = lds + 4 * r16_gstride(K) + row * NC, *invT = GllT + 4 * NC, *stage = invT + 4 * NC;
     const double la = P.lambda * P.alpha, l2 = P.lambda * (1.0 - P.alpha);
     const uint64_t rowmask = 0xffffull << (16 * row);
     bool valid[SLOTS];
@@ -208,6 +223,8 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
 #define R16_S(T) r16_step<SLOTS, T>(S, L, ordw, la, i);
 #define R16_B(B) if (4 * (B) < K) { R16_S(4 * (B)) R16_S(4 * (B) + 1) R16_S(4 * (B) + 2) R16_S(4 * (B) + 3) }
         R16_B(0) R16_B(1) R16_B(2) R16_B(3) R16_B(4) R16_B(5) R16_B(6) R16_B(7)
+        if constexpr (SLOTS > 2) { R16_B(8) R16_B(9) R16_B(10) R16_B(11) }
+        if constexpr (SLOTS > 3) { R16_B(12) R16_B(13) R16_B(14) R16_B(15) }
 #undef R16_B
 #undef R16_S
         ++sweep;
@@ -274,7 +291,7 @@ __global__ void __launch_bounds__(64) k_cd_cols_r16(ColArgs a)
     const int slot = blockIdx.x * 4 + row;
     const int j = slot < a.p ? (a.gene_perm ? a.gene_perm[slot] : slot) : a.p;
     const bool gene = j < a.p;
-    double *Gg = r16_lds + row * K * K;
+    double *Gg = r16_lds + row * r16_gstride(K);
     const double *st = (a.stat && gene) ? a.stat + (size_t)j * a.stat_len : nullptr;
     // XtX_j = R'R - complement (src/optimize.cpp:218-219), or the shared R'R (:234); zero diagonal in LDS
     double q[SLOTS], Gll[SLOTS], beta[SLOTS];
@@ -324,7 +341,7 @@ __global__ void __launch_bounds__(64) k_cd_cols_r16(ColArgs a)
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         const int c = 16 * u + i;
-        col[u] = row * K * K * 8 + (c < K ? c : 0) * 8;
+        col[u] = row * r16_gstride(K) * 8 + (c < K ? c : 0) * 8;
         g[u] = (gene && c < K) ? q[u] - Gll[u] * beta[u] : 0.0;
     }
     r16_gemv<SLOTS>(g, beta, col, L, K, K * 8);
@@ -344,7 +361,7 @@ __global__ void __launch_bounds__(64) k_cd_cols_r16(ColArgs a)
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) rb[u] = 0.0;
 #define R16_D(M) r16_dense_mv_step<SLOTS, M>(rb, beta, a.RtR, KP, K, i, gene);
-        R16_UNROLL32(R16_D)
+        R16_UNROLL64(R16_D)
 #undef R16_D
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
@@ -372,7 +389,7 @@ k_cd_batch_r16(const double *__restrict__ XtX, const double *__restrict__ Xty, c
     const int row = lane >> 4, i = lane & 15;
     const int64_t b = (int64_t)blockIdx.x * 4 + row;
     const bool prob = b < nprob;
-    double *Gg = r16_lds + row * K * K;
+    double *Gg = r16_lds + row * r16_gstride(K);
     double q[SLOTS], Gll[SLOTS], beta[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {

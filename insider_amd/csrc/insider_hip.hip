@@ -473,6 +473,21 @@ int launch_mm_reduce_kp(insider_hip_handle *h, const double *X, int64_t ldx, con
     return INSIDER_OK;
 }
 
+// the row16 kernel with three slots keeps up to 4 x 48 x 48 doubles of Gram matrices per wave in LDS (72 KB): beyond the 64 KB a
+// kernel may ask for dynamically without opting in
+int r16_wide_lds(size_t bytes)
+{
+    if (bytes > 160 * 1024) return fail(INSIDER_ERR_UNSUPPORTED, "K too large for the LDS-resident sweep kernel");
+    static std::atomic<bool> done{false};
+    if (!done.load()) {
+        const int lim = 160 * 1024;
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cd_cols_r16<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cd_batch_r16<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        done.store(true);
+    }
+    return INSIDER_OK;
+}
+
 int launch_gram(insider_hip_handle *h, const double *F, int64_t rows, double *out, hipStream_t st = nullptr,
                 double *part = nullptr)
 {
@@ -874,6 +889,13 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
             hipLaunchKernelGGL((k_cd_cols_r16<2>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
         else if (h->K <= 16) hipLaunchKernelGGL((k_cd_cols<16, 4>), dim3(cdiv(h->p, 16)), dim3(256), 0, h->stream, a);
         else if (h->K <= 32) hipLaunchKernelGGL((k_cd_cols<32, 2>), dim3(cdiv(h->p, 4)), dim3(128), 0, h->stream, a);
+        else if (h->cd_variant != 1 && h->K <= 48) {
+            // 32 < K <= 48: four genes per wavefront with the Gram matrices in LDS (row16 kernel, three coordinate slots per lane;
+            // round 4: 1.9 x the one-gene-per-wavefront kernel at K = 40).  Beyond 48 a CU's LDS holds one such wave and the
+            // kernel below is faster; it also stays as cd_variant = 1 (cross-check)
+            if (int rl = r16_wide_lds(r16_bytes)) return rl;
+            hipLaunchKernelGGL((k_cd_cols_r16<3>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
+        }
         else hipLaunchKernelGGL((k_cd_cols<64, 1>), dim3((unsigned)h->p), dim3(64), 0, h->stream, a);
         KCHECK();
     }
@@ -2379,6 +2401,10 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
                                            nprob, cd, db, ds));
     } else if (K <= 16) hipLaunchKernelGGL((k_cd_batch<16, 4>), dim3(cdiv(nprob, 16)), dim3(256), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32) hipLaunchKernelGGL((k_cd_batch<32, 2>), dim3(cdiv(nprob, 4)), dim3(128), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
+    else if (K <= 48 && !(var && std::atoi(var) == 1)) {   // 32 < K <= 48: the LDS-resident row16 solver (INSIDER_CD_VARIANT=1: one problem per wavefront)
+        if (int rl = r16_wide_lds(r16_bytes)) return rl;
+        hipLaunchKernelGGL((k_cd_batch_r16<3>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
+    }
     else hipLaunchKernelGGL((k_cd_batch<64, 1>), dim3((unsigned)nprob), dim3(64), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     KCHECK();
     HIPCHECK(hipEventRecord(e1, 0));

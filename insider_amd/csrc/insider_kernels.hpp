@@ -369,7 +369,7 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
 
 // Order table, one row of ORDER_ROW bytes per sweep s < nsweeps: bytes [0, 64): the K coordinates in ascending key
 // order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
-// the row16 kernel, K <= 32); bytes [128, 320): 48 uint32, the code-block offsets of the register-resident kernel
+// the row16 kernel; K > 32: 64 of them, bytes [64, 192)); bytes [128, 320), K <= 32: 48 uint32, the code-block offsets of the register-resident kernel
 // (insider_cd_reg.hpp) as a successor list: dword 0 = INSIDER_REG_BLOCK * (first coordinate of the sweep), dword 1 + k = INSIDER_REG_BLOCK * (the
 // coordinate visited after k), exit_block for the last one and for k >= K.  One thread per (sweep, coordinate): rank
 // by counting.
@@ -395,14 +395,18 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     __syncthreads();
     if (!live) return;
     uint32_t *blk = reinterpret_cast<uint32_t *>(row + 128);
+    // K > 32 (row16 kernel with three or four slots): 64 row offsets in bytes [64, 192) and no successor list — the
+    // register-resident kernel, whose list shares those bytes, does not exist there
+    const bool wide = K > 32;
     if (l >= K) {
         row[l] = 0;
-        if (l < 32) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
-        if (l < 47) blk[1 + l] = (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
+        if (l < 32 || wide) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
+        if (l < 47 && !wide) blk[1 + l] = (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
         return;
     }
     row[rank] = (uint8_t)l;
-    if (rank < 32) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
+    if (rank < 32 || wide) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
+    if (wide) return;
     if (l < 47) blk[1 + l] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * (uint32_t)INSIDER_REG_BLOCK : (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
     if (rank == 0) blk[0] = (uint32_t)l * (uint32_t)INSIDER_REG_BLOCK;
 }

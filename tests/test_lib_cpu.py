@@ -209,3 +209,26 @@ def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_detected(tmp_path):
+    """The benchmarked binary must provably be the committed source: the library reports the hash of the
+    sources it was compiled from (insider_hip_version(): 'src:<sha16>' over csrc/, include/ and the flags), build() / _lib.load()
+    compare it with the sources ON DISK by content — not by mtime — and rebuild on a mismatch.  Here: the in-tree library matches;
+    a copy whose embedded hash is altered (what a binary built from other sources looks like) is reported stale; so is a missing one."""
+    import shutil
+    from insider_amd import _build, _lib
+    assert not _build.needs_build(), (_build.library_sha(), _build.source_sha())
+    assert _lib.library_source_sha() == _build.source_sha() == _build.library_sha()
+    assert _lib.load().insider_hip_version().decode().endswith("src:" + _build.source_sha())
+    stale = str(tmp_path / "libinsider_hip_stale.so")
+    shutil.copy(_build.HIP_LIB, stale)
+    blob = open(stale, "rb").read()
+    tag = ("src:" + _build.source_sha()).encode()
+    assert blob.count(tag) >= 1
+    open(stale, "wb").write(blob.replace(tag, b"src:" + b"0" * 16))
+    assert _build.library_sha(stale) == "0" * 16 and _build.needs_build(stale)
+    assert _build.needs_build(str(tmp_path / "missing.so"))
+    # a newer mtime on an up-to-date library changes nothing (the old rule would have trusted / distrusted it by time)
+    os.utime(_build.HIP_LIB, None)
+    assert not _build.needs_build()
