@@ -1,4 +1,4 @@
-"""The periodic sweep-order table on the DEVICE (include/insider_perm.h, DESIGN 4.2f): the library and the oracle are both
+"""The periodic sweep-order table on the DEVICE (include/insider_perm.h, DESIGN 4.2): the library and the oracle are both
 rebuilt with a period of 64 sweeps, and solves of several hundred sweeps are compared — identical per-gene sweep counts and
 iterates across the wrap, in all three CD kernels, through insider_hip_strong_cd, and in multi-pass solves whose pass limits
 and resume points lie beyond the period.  (The production period, 16384, would need solves of > 16384 sweeps per case.)"""
