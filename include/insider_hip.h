@@ -119,9 +119,10 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * the order sequence, INSIDER_PERM_PERIOD = 16384 rows, whatever the cap; insider_hip_get_info("cap_hits") counts the solves
  * of the last call that the cap ended), "order_mode" (0 = hashed random order of
  * include/insider_perm.h, 1 = cyclic), "profile" (1 = time the statistics / solve kernels with HIP events),
- * "verbose" (1 = print the reference's per-checkpoint lines to stdout), "cd_variant" (elastic-net sweep kernel for
- * K <= 32: 0 = four genes per wavefront with the Gram matrix in registers, 2 = four genes per wavefront with the Gram
- * matrix in LDS, 1 = one lane group per gene; all three produce the same iterates), "row_merged" (1, default = masked
+ * "verbose" (1 = print the reference's per-checkpoint lines to stdout), "cd_variant" (elastic-net sweep kernel:
+ * 0 = four genes per wavefront with the Gram matrix in registers [K <= 32; 32 < K <= 47 with the third coordinate slot's
+ * columns in LDS], 2 = four genes per wavefront with the Gram matrix in LDS [K <= 48], 1 = one lane group per gene [also
+ * what K > 48 takes]; all three follow the same sweep orders and agree to rounding), "row_merged" (1, default = masked
  * row update from per-(level, gene) weighted terms, 0 = from per-sample statistics; same results), "col_factored" (1,
  * default = a cost model picks the form of the column-side masked Gram statistics, 0 = one rank-one update per held-out
  * entry, 2 = per-(covariate, level) terms with one table look-up per entry, 3 = per-(covariate, level) terms from the
@@ -129,7 +130,7 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * level-pair counts when they exist, 0 = from the entry lists; same results), "force_allreduce" (1 = call the all-reduce callback even
  * when world == 1: plumbing rehearsal), "cd_split" / "cd_long_frac" (2 = steady-state column steps run split: the genes predicted longest — whole buckets of the
  * launch order, at most cd_long_frac [0.03] of the genes — get their statistics and their solve on a stream of their own, ahead
- * of the others' statistics; bit-identical results; 0 [default] = off: measured, it does not shorten the step, DESIGN.md 4.2e),
+ * of the others' statistics; bit-identical results; 0 [default] = off: measured, it does not shorten the step, DESIGN.md 8),
  * "row_fused" (1, default = the merged row update forms a level's equations and
  * solve in one launch), "row_gemm" / "row_gemm_waves" (1, default = the per-level weighted Gram sums of a covariate with >= 49
  * levels come from one GEMM over genes, cut into row_gemm_waves [1024] waves; 0 = one weighted rank-one update per (level, gene);

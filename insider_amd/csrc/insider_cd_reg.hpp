@@ -1,5 +1,6 @@
 // insider_cd_reg.hpp — register-resident elastic-net coordinate descent for K <= 32: four genes per wavefront,
-// the Gram matrix in VGPRs, no LDS.
+// the Gram matrix in VGPRs, no LDS; and for 32 < K <= 47 with a third coordinate slot whose Gram columns live in LDS
+// (REG_DEFINE_SWEEP3 below).
 //
 // strong_coordinate_descent's sweep loop (src/coordinate_descent.cpp:86-114) is a K-step sequential recurrence per
 // gene that runs for hundreds to thousands of sweeps; it is bound by vector-instruction issue.  Layout: gene g owns
@@ -57,7 +58,7 @@ struct RegState {
 // update alone, but the part sustains a higher clock (round 3, tools/ab_variants.sh: +4 % sweep rate, bit-identical).
 // The address add sits between the clamp and the subtraction that depends on it (round 4: in the shadow of the clamp's
 // result latency instead of in front of the chain, sweep kernel 2.08 -> 2.00 ms per launch at c3, tools/exp_probe.sh).
-// Measured and NOT adopted in round 4 (same tool; DESIGN 4.2h): the head on all lanes with the beta update as a bank-masked
+// Measured and NOT adopted in round 4 (same tool; DESIGN 4.2): the head on all lanes with the beta update as a bank-masked
 // DPP fmac on a lane indicator (no exec writes: slower, 2.17-2.24 ms — four more full-width fp64 instructions per step
 // cost more clock than the two exec writes cost issue slots); wave priorities by hardware wave id (slower); the exec
 // narrowing after the clamp (slower); other positions of the add (equal).
@@ -165,15 +166,141 @@ __device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][1
 #endif
 }
 
+// ---- 32 < K <= 47: three coordinate slots, the third slot's Gram columns in LDS (round 4) ---------------------------------
+// Lane i also owns coordinate 32 + i (i < KMAX - 32).  Columns i and 16 + i of the Gram matrix stay in VGPRs (4 KMAX of the 256
+// a wave may hold at two waves per SIMD); column 32 + i lives in an LDS panel of this wave — row k at byte k * PS, PS = (4 W + 1) * 8,
+// W = KMAX - 32 coordinates per gene, cell g * W + i for lane i < W of gene row g, and ONE zero cell (4 W) per row that every lane
+// without a third coordinate reads (so its y stays what it was).  Inside block k the panel row is static like the register
+// operands: `ds_read_b64 gc, la offset:k*PS` is the block's first instruction, the third DPP fmac waits for it behind the two
+// register ones.  Per step 7 vector + 1 LDS + 4 scalar instructions + the wait.  The successor list takes 48 dwords (dword 0 +
+// one per coordinate: K <= 47) in s[48:95]; the block table is longer than 4 KiB here and aligned to 8 KiB.
+constexpr int reg3_w(int KMAX) { return KMAX - 32; }
+constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // panel row pitch in doubles
+#define REG3_HEAD(KK, HS, BS, IS, IT)                                        \
+    REG_ORG(KK)                                                              \
+    "ds_read_b64 %[gc], %[la] offset:(" #KK "*" REG3_PS_STR ")\n"            \
+    "s_lshl_b64 exec, %[lm], " #IT "\n"                                      \
+    "v_max_f64 %[dn], %[" HS "], %[" HS "] clamp\n"                          \
+    "s_add_u32 vcc_lo, s[49+" #KK "], s98\n"                                 \
+    "v_add_f64 %[dn], %[" HS "], -%[dn]\n"                                   \
+    "v_fma_f64 %[dn], -%[dn], %[" IS "], %[" BS "]\n"                        \
+    "v_fmac_f64 %[" BS "], -1.0, %[dn]\n"                                    \
+    "s_mov_b64 exec, -1\n"
+#define REG3_TAIL(KK, IT)                                                                            \
+    REG_FMAC("h0", "ga" #KK, IT)                                                                     \
+    REG_FMAC("h1", "gb" #KK, IT) "s_waitcnt lgkmcnt(0)\n"                                            \
+    "v_fmac_f64_dpp %[h2], %[dn], %[gc] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n" REG_JUMP
+#define REG3_BLOCK_LO(KK) REG3_HEAD(KK, "h0", "b0", "i0", KK) REG3_TAIL(KK, KK)
+#define REG3_BLOCK_MID(KK, IT) REG3_HEAD(KK, "h1", "b1", "i1", IT) REG3_TAIL(KK, IT)
+#define REG3_BLOCK_TOP(KK, IT) REG3_HEAD(KK, "h2", "b2", "i2", IT) REG3_TAIL(KK, IT)
+#define REG3_PROLOGUE                              \
+    "s_load_dwordx16 s[48:63], %[tb], 0x0\n"       \
+    "s_load_dwordx16 s[64:79], %[tb], 0x40\n"      \
+    "s_load_dwordx16 s[80:95], %[tb], 0x80\n"      \
+    "s_getpc_b64 s[98:99]\n"                       \
+    "Lr%=:\n"                                      \
+    "s_add_u32 s98, s98, Lc%=-Lr%=\n"              \
+    "s_addc_u32 s99, s99, 0\n"                     \
+    "s_mov_b32 vcc_hi, s99\n"                      \
+    "s_waitcnt lgkmcnt(0)\n"                       \
+    "s_load_dword %[sk], %[tb], 0x140\n"           \
+    "s_load_dword %[p1], %[tb], 0x180\n"           \
+    "s_load_dword %[p2], %[tb], 0x1c0\n"           \
+    "s_add_u32 vcc_lo, s48, s98\n"                 \
+    "s_setpc_b64 vcc\n.p2align 13\n"              \
+    "Lc%=:\n"
+#define REG3_CLOBBERS REG_CLOBBERS, "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
+#define REG_T1_36(F) F(32) F(33) F(34) F(35)
+#define REG_T1_40(F) REG_T1_36(F) F(36) F(37) F(38) F(39)
+#define REG_T1_44(F) REG_T1_40(F) F(40) F(41) F(42) F(43)
+#define REG_T1_48(F) REG_T1_44(F) F(44) F(45) F(46) F(47)
+#define REG_TB_36(F) F(32, 0) F(33, 1) F(34, 2) F(35, 3)
+#define REG_TB_40(F) REG_TB_36(F) F(36, 4) F(37, 5) F(38, 6) F(39, 7)
+#define REG_TB_44(F) REG_TB_40(F) F(40, 8) F(41, 9) F(42, 10) F(43, 11)
+#define REG_TB_48(F) REG_TB_44(F) F(44, 12) F(45, 13) F(46, 14) F(47, 15)
+// la: LDS byte address of this lane's cell in row 0 of the panel
+#if defined(__HIP_DEVICE_COMPILE__)
+#define REG_DEFINE_SWEEP3(KMAX)                                                                                          \
+    __device__ __forceinline__ void reg_sweep(RegState<3> &S, const double (&G)[2][KMAX], const uint32_t *tb, uint32_t la) \
+    {                                                                                                                    \
+        double dn, gc;                                                                                                   \
+        int sk, p1, p2;                                                                                                  \
+        const uint64_t lm = 0x0001000100010001ull;                                                                       \
+        asm volatile(REG3_PROLOGUE REG_LIST_LO(REG3_BLOCK_LO) REG_HB_32(REG3_BLOCK_MID) REG_TB_##KMAX(REG3_BLOCK_TOP)    \
+                         REG_EPILOGUE(KMAX)                                                                              \
+                     : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [h2] "+v"(S.y[2]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), \
+                       [b2] "+v"(S.beta[2]), [dn] "=&v"(dn), [gc] "=&v"(gc), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2) \
+                     : REG_LIST_LO(REG_GA) REG_HI_32(REG_GA) REG_T1_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_32(REG_GB)   \
+                           REG_T1_##KMAX(REG_GB)[i0] "v"(S.tau[0]),                                                      \
+                       [i1] "v"(S.tau[1]), [i2] "v"(S.tau[2]), [tb] "s"(tb), [lm] "s"(lm), [la] "v"(la)                  \
+                     : REG3_CLOBBERS);                                                                                   \
+    }
+#else
+#define REG_DEFINE_SWEEP3(KMAX) \
+    __device__ __forceinline__ void reg_sweep(RegState<3> &, const double (&)[2][KMAX], const uint32_t *, uint32_t) {}
+#endif
+#define REG3_PS_STR "136"
+REG_DEFINE_SWEEP3(36)
+#undef REG3_PS_STR
+#define REG3_PS_STR "264"
+REG_DEFINE_SWEEP3(40)
+#undef REG3_PS_STR
+#define REG3_PS_STR "392"
+REG_DEFINE_SWEEP3(44)
+#undef REG3_PS_STR
+#define REG3_PS_STR "520"
+REG_DEFINE_SWEEP3(48)
+#undef REG3_PS_STR
+static_assert(reg3_ps(36) * 8 == 136 && reg3_ps(40) * 8 == 264 && reg3_ps(44) * 8 == 392 && reg3_ps(48) * 8 == 520, "REG3_PS_STR");
+
 // waves per SIMD the register budget of an instantiation is sized for (512 VGPRs per SIMD lane)
 #ifndef INSIDER_REG_4WAVE_MAX
 #define INSIDER_REG_4WAVE_MAX 20   // largest KMAX built for 4 waves per SIMD (128 VGPRs)
 #endif
-__host__ __device__ constexpr int reg_waves(int KMAX) { return KMAX <= INSIDER_REG_4WAVE_MAX ? 4 : 3; }
+__host__ __device__ constexpr int reg_waves(int KMAX) { return KMAX <= INSIDER_REG_4WAVE_MAX ? 4 : (KMAX <= 32 ? 3 : 2); }
 // smallest instantiated KMAX >= K
-__host__ __device__ constexpr int reg_kmax(int K) { return K <= 16 ? 16 : (K + 1) & ~1; }
+__host__ __device__ constexpr int reg_kmax(int K) { return K <= 16 ? 16 : (K <= 32 ? (K + 1) & ~1 : (K + 3) & ~3); }
+// register slots of an instantiation (the third slot's Gram columns live in LDS)
+__host__ __device__ constexpr int reg_rs(int SLOTS) { return SLOTS < 3 ? SLOTS : 2; }
+// the wave's panel of third-slot Gram columns (SLOTS == 3), else nothing
+template <int SLOTS, int KMAX>
+struct RegPanel {
+    static __device__ __forceinline__ double *get() { return nullptr; }
+};
+template <int KMAX>
+struct RegPanel<3, KMAX> {
+    static __device__ __forceinline__ double *get()
+    {
+        __shared__ double panel[KMAX * reg3_ps(KMAX)];
+        return panel;
+    }
+};
+// this lane's cell of a panel row: its own third coordinate's, or the row's zero cell
+template <int KMAX>
+__device__ __forceinline__ int reg3_cell(int lane)
+{
+    const int i = lane & 15;
+    return i < reg3_w(KMAX) ? (lane >> 4) * reg3_w(KMAX) + i : 4 * reg3_w(KMAX);
+}
 
-// acc[u] -= sum_{m < K} G[u][m] * v_m  (v in coordinate order)
+// acc[u] -= sum_{m < K} G[u][m] * v_m  (v in coordinate order); three slots: pc = this lane's cell in row 0 of the panel
+template <int KMAX>
+__device__ __forceinline__ void reg_gemv3(double (&acc)[3], const double (&v)[3], const double (&G)[2][KMAX], int K,
+                                          const double *pc)
+{
+#define REG_G(M)                                                                                        \
+    if constexpr ((M) < KMAX) {                                                                         \
+        if ((M) < K) {                                                                                  \
+            const double vm = row_bcast<(M) & 15>(v[(M) >> 4]);                                         \
+            acc[0] = fma(-vm, G[0][(M)], acc[0]);                                                       \
+            acc[1] = fma(-vm, G[1][(M)], acc[1]);                                                       \
+            acc[2] = fma(-vm, pc[(M) * reg3_ps(KMAX)], acc[2]);                                         \
+        }                                                                                               \
+    }
+    R16_UNROLL32(REG_G) REG_T1_48(REG_G)
+#undef REG_G
+}
+
 template <int SLOTS, int KMAX>
 __device__ __forceinline__ void reg_gemv(double (&acc)[SLOTS], const double (&v)[SLOTS], const double (&G)[SLOTS][KMAX],
                                          int K)
@@ -195,6 +322,10 @@ __device__ __forceinline__ void reg_gemv(double (&acc)[SLOTS], const double (&v)
 constexpr int REG_STASH = 6 * 2 * 64;   // D, beta0, w0, solution | two 64-entry windows of |loss change| sums (multi-pass:
                                         // remaining-length estimate) | 1 / D (for the KKT re-admission, :123: no division
                                         // and none of its temporaries inside the sweep loop)
+// the same for any slot count: arrays of S = 64 x slots (128 up to two slots) doubles at 0, S, 2S, 3S; the windows at 4S; 1 / D at 4S + 128
+__host__ __device__ constexpr int reg_sa(int SLOTS) { return SLOTS < 3 ? 128 : 64 * SLOTS; }
+__host__ __device__ constexpr int reg_stash(int SLOTS) { return 5 * reg_sa(SLOTS) + 128; }
+static_assert(reg_stash(2) == REG_STASH && reg_stash(1) == REG_STASH, "stash layout");
 
 // The solver, in two parts: cd_reg_begin (start values from q, Gll, the warm start / the saved state; no matrix) and cd_reg
 // (the sweeps).  G: columns 16u + i of the row's Gram matrix (zero diagonal).  q, Gll, beta: coordinate 16u + i of
@@ -223,7 +354,8 @@ __device__ __forceinline__ RegState<SLOTS> cd_reg_begin(int K, const double (&q)
 {
     const int i = lane & 15;
     const double l2 = P.l2, two_la = P.two_la, gs = P.inv_two_la;   // the scaled state: RegState
-    double *s_d = stash + lane, *s_out = s_d + 384, *s_ri = s_d + 640;   // [slot * 64]
+    constexpr int SA = reg_sa(SLOTS);
+    double *s_d = stash + lane, *s_out = s_d + 3 * SA, *s_ri = s_d + 4 * SA + 128;   // [slot * 64]
     RegState<SLOTS> S;
     if (!resume) {
         // ---- strong rule and start values (:74-80) -----------------------------------------------------------
@@ -261,9 +393,10 @@ __device__ __forceinline__ RegState<SLOTS> cd_reg_begin(int K, const double (&q)
 
 // S: the start values of cd_reg_begin; beta / hs / is are outputs here
 template <int SLOTS, int KMAX>
-__device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS][KMAX], int K, double (&beta)[SLOTS],
+__device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[reg_rs(SLOTS)][KMAX], int K, double (&beta)[SLOTS],
                                       bool gene_ok, const CdParams &P, int lane, double *stash, bool resume,
-                                      double (&hs)[SLOTS], double (&is)[SLOTS], bool &unfinished, int &key, bool &capped)
+                                      double (&hs)[SLOTS], double (&is)[SLOTS], bool &unfinished, int &key, bool &capped,
+                                      const double *panel = nullptr)
 {
     const int i = lane & 15;
     // the scalars the sweep loop needs, copied out of the kernel-argument tuple: the sweep's assembly clobbers s63-s99,
@@ -274,15 +407,24 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(la), "+s"(tol), "+s"(two_la), "+s"(max_sweeps), "+s"(order));
 #endif
-    double *s_d = stash + lane, *s_b = s_d + 128, *s_w = s_d + 256, *s_out = s_d + 384;   // [slot * 64]
-    double *s_acc = s_d + 512;                                                           // [window * 64]
-    const double *s_ri = s_d + 640;                                                      // [slot * 64]
+    constexpr int SA = reg_sa(SLOTS);
+    double *s_d = stash + lane, *s_b = s_d + SA, *s_w = s_d + 2 * SA, *s_out = s_d + 3 * SA;   // [slot * 64]
+    double *s_acc = s_d + 4 * SA;                                                        // [window * 64]
+    const double *s_ri = s_d + 4 * SA + 128;                                             // [slot * 64]
     s_acc[0] = 0.0;
     s_acc[64] = 0.0;
     unfinished = false;
     capped = false;
     key = 0;
-    if (!resume) reg_gemv<SLOTS, KMAX>(S.y, S.beta, G, K);                                // :79 h = q - offdiag(XtX) beta (G scaled)
+    uint32_t pla = 0;   // three slots: LDS byte address of this lane's cell in row 0 of the panel
+    if constexpr (SLOTS == 3) {
+        typedef __attribute__((address_space(3))) const double lds_cd;
+        const double *pc = panel + reg3_cell<KMAX>(lane);
+        pla = (uint32_t)(uintptr_t)(lds_cd *)pc;
+        if (!resume) reg_gemv3<KMAX>(S.y, S.beta, G, K, pc);
+    } else {
+        if (!resume) reg_gemv<SLOTS, KMAX>(S.y, S.beta, G, K);                            // :79 h = q - offdiag(XtX) beta (G scaled)
+    }
     // loss bookkeeping in the scaled units too: what = w / (2 la) - 1/2 = beta D / (2 la) - y, w = beta D - h (below)
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
@@ -309,7 +451,8 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[SLOTS
     const uint32_t *tb = tb0 + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * (ORDER_ROW / 4);
     while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
-        reg_sweep(S, G, tb);
+        if constexpr (SLOTS == 3) reg_sweep(S, G, tb, pla);
+        else reg_sweep(S, G, tb);
         ++sweep;
         tb = (sweep & (int)(INSIDER_PERM_PERIOD - 1)) ? tb + ORDER_ROW / 4 : tb0;
         // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
@@ -448,8 +591,10 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
     const int K = a.K, KP = a.KP;
     const bool resume = a.resume != 0;
     const double gs = a.cd.inv_two_la;
-    __shared__ double stash[REG_STASH];
-    double G[SLOTS][KMAX], beta[SLOTS], hs[SLOTS], is[SLOTS];
+    static_assert(SOLVE || SLOTS < 3, "three slots: the loss statistics come from k_cd_cols_r16<3> (COL_EVAL)");
+    __shared__ double stash[reg_stash(SLOTS)];
+    double *const panel = RegPanel<SLOTS, KMAX>::get();
+    double G[reg_rs(SLOTS)][KMAX], beta[SLOTS], hs[SLOTS], is[SLOTS];
     bool unfinished = false, capped = false;
     int key = 0, sweeps = 0;
     {
@@ -492,11 +637,18 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
                 const int si = bk >= u ? (bk * (bk + 1) / 2 + u) * 256 + (k & 15) * 16 + w.i
                                        : (u * (u + 1) / 2 + bk) * 256 + w.i * 16 + (k & 15);
                 const double v = w.st ? w.st[si] : a.RtR[k * KP + c];
-                G[u][k] = (ok && k < K && k != c) ? (SOLVE ? v * gs : v) : 0.0;   // the sweeps work on XtX / (2 la): RegState
+                const double gv = (ok && k < K && k != c) ? (SOLVE ? v * gs : v) : 0.0;   // the sweeps work on XtX / (2 la): RegState
+                if constexpr (SLOTS == 3) {
+                    if (u < 2) G[u < 2 ? u : 0][k] = gv;
+                    else if (k < K) panel[k * reg3_ps(KMAX) + reg3_cell<KMAX>(lane)] = gv;   // (lanes without a third coordinate: 0 into the row's zero cell)
+                } else {
+                    G[u][k] = gv;
+                }
             }
         }
+        if constexpr (SLOTS == 3) wave_sync();
         if constexpr (SOLVE)                                                              // :228,246
-            sweeps = cd_reg<SLOTS, KMAX>(S, G, K, beta, w.gene, a.cd, lane, stash, resume, hs, is, unfinished, key, capped);
+            sweeps = cd_reg<SLOTS, KMAX>(S, G, K, beta, w.gene, a.cd, lane, stash, resume, hs, is, unfinished, key, capped, panel);
     }
     // ---- results: everything that addresses the gene is formed again, from a laundered lane id ------------------------
     int lane_c = lane;
@@ -546,7 +698,7 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
     reg_load_q<SLOTS>(a, w, q, Gll);
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) g[u] = (w.gene && 16 * u + w.i < K) ? q[u] - Gll[u] * beta[u] : 0.0;
-    reg_gemv<SLOTS, KMAX>(g, beta, G, K);
+    if constexpr (SLOTS < 3) reg_gemv<SLOTS, KMAX>(g, beta, G, K);   // (three slots: SOLVE only, this part is dead code there)
     double t_bqg = 0.0, t_b2 = 0.0, t_b1 = 0.0, t_te = 0.0;
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
@@ -588,8 +740,9 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
                int64_t nprob, CdParams cd, double *__restrict__ beta_out, int *__restrict__ sweeps_out)
 {
     const int lane = threadIdx.x;
-    __shared__ double stash[REG_STASH];
-    double G[SLOTS][KMAX], beta[SLOTS];
+    __shared__ double stash[reg_stash(SLOTS)];
+    double *const panel = RegPanel<SLOTS, KMAX>::get();
+    double G[reg_rs(SLOTS)][KMAX], beta[SLOTS];
     int sw;
     {
         const int row = lane >> 4, i = lane & 15;
@@ -625,12 +778,19 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 const double v = Gb[(size_t)(k < K ? k : 0) * K + cc];
-                G[u][k] = (ok && k < K && k != c) ? v * cd.inv_two_la : 0.0;   // the sweeps work on XtX / (2 la): RegState
+                const double gv = (ok && k < K && k != c) ? v * cd.inv_two_la : 0.0;   // the sweeps work on XtX / (2 la): RegState
+                if constexpr (SLOTS == 3) {
+                    if (u < 2) G[u < 2 ? u : 0][k] = gv;
+                    else if (k < K) panel[k * reg3_ps(KMAX) + reg3_cell<KMAX>(lane)] = gv;
+                } else {
+                    G[u][k] = gv;
+                }
             }
         }
+        if constexpr (SLOTS == 3) wave_sync();
         bool unfinished, capped;
         int key;
-        sw = cd_reg<SLOTS, KMAX>(S, G, K, beta, prob, cd, lane, stash, false, hs, is, unfinished, key, capped);
+        sw = cd_reg<SLOTS, KMAX>(S, G, K, beta, prob, cd, lane, stash, false, hs, is, unfinished, key, capped, panel);
     }
     int lane_c = lane;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -657,6 +817,30 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
         case 28: { constexpr int SL_ = 2, KM_ = 28; CALL; } break; \
         case 30: { constexpr int SL_ = 2, KM_ = 30; CALL; } break; \
         default: { constexpr int SL_ = 2, KM_ = 32; CALL; } break; \
+    }
+// 32 < K <= 47: three slots
+#define REG3_DISPATCH(K, CALL)                                     \
+    switch (reg_kmax(K)) {                                         \
+        case 36: { constexpr int SL_ = 3, KM_ = 36; CALL; } break; \
+        case 40: { constexpr int SL_ = 3, KM_ = 40; CALL; } break; \
+        case 44: { constexpr int SL_ = 3, KM_ = 44; CALL; } break; \
+        default: { constexpr int SL_ = 3, KM_ = 48; CALL; } break; \
+    }
+#define REG_ANY_DISPATCH(K, CALL)                                  \
+    switch (reg_kmax(K)) {                                         \
+        case 16: { constexpr int SL_ = 1, KM_ = 16; CALL; } break; \
+        case 18: { constexpr int SL_ = 2, KM_ = 18; CALL; } break; \
+        case 20: { constexpr int SL_ = 2, KM_ = 20; CALL; } break; \
+        case 22: { constexpr int SL_ = 2, KM_ = 22; CALL; } break; \
+        case 24: { constexpr int SL_ = 2, KM_ = 24; CALL; } break; \
+        case 26: { constexpr int SL_ = 2, KM_ = 26; CALL; } break; \
+        case 28: { constexpr int SL_ = 2, KM_ = 28; CALL; } break; \
+        case 30: { constexpr int SL_ = 2, KM_ = 30; CALL; } break; \
+        case 32: { constexpr int SL_ = 2, KM_ = 32; CALL; } break; \
+        case 36: { constexpr int SL_ = 3, KM_ = 36; CALL; } break; \
+        case 40: { constexpr int SL_ = 3, KM_ = 40; CALL; } break; \
+        case 44: { constexpr int SL_ = 3, KM_ = 44; CALL; } break; \
+        default: { constexpr int SL_ = 3, KM_ = 48; CALL; } break; \
     }
 
 }  // namespace insider

@@ -548,7 +548,10 @@ struct Timer {   // HIP-event pair around one launch on the library's stream (op
 // (h->order) when its solve is launched.  Two buffers: an outer iteration's table depends on (seed, iter) only, so the NEXT one
 // is built while the current solve runs — the sweep kernel leaves no room for other waves, so the builder runs in its tail,
 // on SIMDs that have already drained — instead of competing with the row phase.
-int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode,
+// 32 < K <= 47 with an l1 term: the register-resident kernel with its third slot's matrix columns in LDS (insider_cd_reg.hpp)
+static bool reg3_path(int K, double la, int variant) { return K > 32 && K <= 47 && la > 0.0 && variant == 0; }
+
+int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode, double la,
                        hipStream_t stream = nullptr, int slot = 0)
 {
     if (!stream) stream = h->stream;
@@ -563,8 +566,9 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
         }
         h->order_rows = rows;
     }
+    // rows for K > 32 carry 64 row offsets (row16 kernel) unless the solve takes the register-resident kernel's successor list
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)(rows + 1) * 64, 256)), dim3(256), 0, stream, seed, iter, K, rows,
-                       order_mode, K * 8, reg_kmax(K), h->order_buf[slot]);
+                       order_mode, K * 8, reg_kmax(K), (K > 32 && !reg3_path(K, la, h->cd_variant)) ? 1 : 0, h->order_buf[slot]);
     KCHECK();
     if (!h->order) h->order = h->order_buf[slot];
     return INSIDER_OK;
@@ -823,7 +827,7 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         const size_t r16_bytes = (size_t)r16_lds_doubles(h->K) * sizeof(double);
         // the register-resident kernel scales its state by 1 / (2 lambda alpha): lambda alpha = 0 (alpha < 0 or lambda = 0: no l1
         // term at all) takes the group kernel below
-        if (h->cd_variant == 0 && h->K <= 32 && a.cd.la > 0.0) {
+        if (h->cd_variant == 0 && (h->K <= 32 || reg3_path(h->K, a.cd.la, 0)) && a.cd.la > 0.0) {
             // Cold outer iterations: thousands of sweeps per gene whose counts no history predicts, so a wave's four genes
             // finish far apart (measured at c3: 1.17x / 1.44x / 2.1x the ideal wave time in outer iterations 0 / 1 / 2).
             // The solve then runs in passes over geometrically growing sweep ranges: a limited pass stops at its sweep
@@ -864,7 +868,7 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
                 a.pass_slot = npass ? h->cd_pass_slot : nullptr;
                 a.bucket_cnt = limit ? h->cd_pass_cnt : nullptr;
                 if (limit) HIPCHECK(hipMemsetAsync(h->cd_pass_cnt, 0, CD_BUCKETS * sizeof(int), h->stream));
-                if (solve) { REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, true>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a)); }
+                if (solve) { REG_ANY_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, true>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, a)); }
                 KCHECK();
                 if (!limit) break;
                 int *count_out = h->cd_pass_cnt + CD_BUCKETS + (pass & 1);
@@ -905,7 +909,14 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         eval_args.pass_count = nullptr;
         eval_args.slot_begin = nullptr;
         eval_args.resume = 0;
-        REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, false>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, eval_args));
+        if (h->K <= 32) {
+            REG_DISPATCH(h->K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, false>), dim3(cdiv(h->p, 4)), dim3(64), 0, h->stream, eval_args));
+        } else {   // three slots: the row16 kernel's evaluation part (the sweep kernel's registers are all taken)
+            const size_t eb = (size_t)r16_lds_doubles(h->K) * sizeof(double);
+            if (int rl = r16_wide_lds(eb)) return rl;
+            eval_args.mode = COL_EVAL;
+            hipLaunchKernelGGL((k_cd_cols_r16<3>), dim3(cdiv(h->p, 4)), dim3(64), eb, h->stream, eval_args);
+        }
         KCHECK();
     }
     if (solve && alpha != 0.0) {
@@ -2150,14 +2161,14 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
         if ((rc = phase_R(h, true, true))) return rc;
         const int checkpoint = iter % 10 == 0;
         if (alpha != 0.0 && iter == 0)   // later iterations: built on the side stream while the previous solve ran
-            if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode, nullptr, 0))) return rc;
+            if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode, lambda2 * alpha, nullptr, 0))) return rc;
         if (masked) if ((rc = launch_col_stats(h, true, use_split(h, masked, alpha, (int)iter)))) return rc;
         if (alpha != 0.0) {
             h->order = h->order_buf[iter & 1];
             if (iter < max_iter) {   // the next iteration's table, from here on: beside this iteration's solve
                 HIPCHECK(hipEventRecord(h->ev_tab, h->stream));
                 HIPCHECK(hipStreamWaitEvent(h->side, h->ev_tab, 0));
-                if ((rc = ensure_order_table(h, seed, iter + 1, K, h->max_sweeps, h->order_mode, h->side, (int)((iter + 1) & 1))))
+                if ((rc = ensure_order_table(h, seed, iter + 1, K, h->max_sweeps, h->order_mode, lambda2 * alpha, h->side, (int)((iter + 1) & 1))))
                     return rc;
             }
         }
@@ -2345,7 +2356,7 @@ int insider_hip_optimize_col(insider_hip_handle *h, double *const *A, double *C,
     if ((rc = upload_factors(h, A, C, K))) return rc;
     if ((rc = phase_R(h))) return rc;
     if (alpha != 0.0) {
-        if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode, nullptr, 0))) return rc;
+        if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode, lambda * alpha, nullptr, 0))) return rc;
         h->order = h->order_buf[0];
     }
     if (tuning == 1) if ((rc = launch_col_stats(h, false))) return rc;
@@ -2369,8 +2380,12 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
     const int rows = std::min<int64_t>(ms, INSIDER_PERM_PERIOD);   // one period of the order sequence (include/insider_perm.h)
     uint8_t *dord = nullptr;
     if ((rc = bufs.alloc(&dord, (size_t)(rows + 4) * ORDER_ROW))) return rc;   // + the look-ahead row
+    // debugging knob: INSIDER_CD_VARIANT=2 runs the LDS-resident row16 solver instead of the register-resident one, 1 the group kernel
+    const char *var = std::getenv("INSIDER_CD_VARIANT");
+    const int variant = var ? std::atoi(var) : 0;
+    const bool reg3 = reg3_path(K, lambda * alpha, variant);
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)(rows + 1) * 64, 256)), dim3(256), 0, 0, seed, iter, K, rows, order_mode, K * 8,
-                       reg_kmax(K), dord);
+                       reg_kmax(K), (K > 32 && !reg3) ? 1 : 0, dord);
     KCHECK();
     CdParams cd;
     cd.lambda = lambda;
@@ -2388,9 +2403,7 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
     HIPCHECK(hipEventCreate(&e1));
     bufs.events.push_back(e1);
     HIPCHECK(hipEventRecord(e0, 0));
-    // debugging knob: INSIDER_CD_VARIANT=2 runs the LDS-resident row16 solver instead of the register-resident one
-    const char *var = std::getenv("INSIDER_CD_VARIANT");
-    const bool lds_variant = var && std::atoi(var) == 2;
+    const bool lds_variant = variant == 2;
     const size_t r16_bytes = (size_t)r16_lds_doubles(K) * sizeof(double);
     if (K <= 16 && lds_variant)
         hipLaunchKernelGGL((k_cd_batch_r16<1>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
@@ -2401,7 +2414,11 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
                                            nprob, cd, db, ds));
     } else if (K <= 16) hipLaunchKernelGGL((k_cd_batch<16, 4>), dim3(cdiv(nprob, 16)), dim3(256), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32) hipLaunchKernelGGL((k_cd_batch<32, 2>), dim3(cdiv(nprob, 4)), dim3(128), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
-    else if (K <= 48 && !(var && std::atoi(var) == 1)) {   // 32 < K <= 48: the LDS-resident row16 solver (INSIDER_CD_VARIANT=1: one problem per wavefront)
+    else if (reg3) {   // 32 < K <= 47: register-resident with the third slot's matrix columns in LDS
+        REG3_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0, dG, dq, dw, K,
+                                            nprob, cd, db, ds));
+    }
+    else if (K <= 48 && variant != 1) {   // K = 48, lambda alpha = 0 or INSIDER_CD_VARIANT=2: the LDS-resident row16 solver (=1: one problem per wavefront)
         if (int rl = r16_wide_lds(r16_bytes)) return rl;
         hipLaunchKernelGGL((k_cd_batch_r16<3>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
     }

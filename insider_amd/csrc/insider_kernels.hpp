@@ -374,7 +374,7 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
 // coordinate visited after k), exit_block for the last one and for k >= K.  One thread per (sweep, coordinate): rank
 // by counting.
 __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
-                                                     int pitch_bytes, int exit_block, uint8_t *__restrict__ order)
+                                                     int pitch_bytes, int exit_block, int wide_rows, uint8_t *__restrict__ order)
 {
     __shared__ uint8_t by_rank[4][64];
     __shared__ uint32_t keys[4][64];
@@ -395,9 +395,9 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     __syncthreads();
     if (!live) return;
     uint32_t *blk = reinterpret_cast<uint32_t *>(row + 128);
-    // K > 32 (row16 kernel with three or four slots): 64 row offsets in bytes [64, 192) and no successor list — the
-    // register-resident kernel, whose list shares those bytes, does not exist there
-    const bool wide = K > 32;
+    // wide rows (K > 32 on the row16 kernel with three or four slots): 64 row offsets in bytes [64, 192) and no successor list,
+    // which shares those bytes; K <= 47 on the register-resident kernel: the list (1 + K <= 48 dwords), 32 row offsets
+    const bool wide = wide_rows != 0;
     if (l >= K) {
         row[l] = 0;
         if (l < 32 || wide) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;

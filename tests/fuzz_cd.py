@@ -13,7 +13,10 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 bad = 0
 for case in range(ncases):
-    K = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 18, 22, 24, 29, 30, 31, 32, 33, 47, 64]))
+    kchoice = [1, 2, 3, 7, 15, 16, 17, 18, 22, 24, 29, 30, 31, 32, 33, 47, 64]
+    if os.environ.get("FUZZ_K"):
+        kchoice = [int(k) for k in os.environ["FUZZ_K"].split(",")]
+    K = int(rng.choice(kchoice))
     B = int(rng.choice([1, 2, 3, 4, 5, 9, 33]))
     m = int(rng.integers(max(2, K // 2), 3 * K + 20))
     lam = float(rng.choice([1e-3, 0.5, 3.0, 50.0, 1e4]))

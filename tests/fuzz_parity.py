@@ -34,7 +34,10 @@ def draw_case(rng):
         levels = (int(rng.choice([49, 64, 97, 130])),) + levels[1:]
     n = int(rng.integers(max(16, max(levels) * 2), max(260, max(levels) * 3)))
     p = int(rng.integers(5, 140))
-    K = int(rng.choice([1, 2, 3, 5, 8, 13, 15, 16, 17, 20, 23, 25, 30, 31, 32, 33, 40, 47, 48, 63]))
+    kchoice = [1, 2, 3, 5, 8, 13, 15, 16, 17, 20, 23, 25, 30, 31, 32, 33, 40, 47, 48, 63]
+    if os.environ.get("FUZZ_K"):   # e.g. FUZZ_K=33,36,37,41,44,45,47: a sweep over chosen instantiations
+        kchoice = [int(k) for k in os.environ["FUZZ_K"].split(",")]
+    K = int(rng.choice(kchoice))
     tuning = int(rng.random() < 0.8)
     kw = dict(n=n, p=p, level_counts=levels, K=K, f=float(rng.uniform(0.03, 0.6)), lam=float(rng.choice([0.3, 1.0, 2.0, 7.0])),
               alpha=float(rng.choice([0.0, 0.1, 0.4, 0.8, 1.0])), tuning=tuning, seed=int(rng.integers(1, 10 ** 6)),
