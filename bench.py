@@ -519,9 +519,8 @@ def main():
                 "note": ("achieved = executed v_mfma_f64_16x16x4 flops (2048 each) / time against the 78.6 TF f64 matrix peak; the "
                          "per-entry list form of the same statistics (option col_factored = 0) is the streaming-equivalent kernel")},
             "cd_kernel": {"kernel": ("k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)"
-                                     if K <= 32 else ("k_cd_cols_reg<3, .> (32 < K <= 47: the same kernel with three coordinate slots per lane, the third slot's Gram columns in LDS: 7 VALU + 1 LDS read per step, two waves per SIMD)"
-                                                      if K <= 47 else ("k_cd_cols_r16<3> (K = 48: four genes per wavefront, Gram matrices in LDS, state permuted per sweep, DPP broadcasts)"
-                                                                       if K <= 48 else "k_cd_cols<64, 1> (K > 48: one gene per wavefront, Gram matrix in LDS, v_readlane broadcasts)"))),
+                                     if K <= 32 else ("k_cd_cols_reg<3, .> (32 < K <= 48: the same kernel with three coordinate slots per lane, the third slot's Gram columns in LDS: 7 VALU + 1 LDS read per step, two waves per SIMD)"
+                                                      if K <= 48 else "k_cd_cols<64, 1> (K > 48: one gene per wavefront, Gram matrix in LDS, v_readlane broadcasts)")),
                           "avg_launch_ms": cd_ms, "traffic": tr_cd,
                           "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,
                           "coordinate_updates_per_s": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9),

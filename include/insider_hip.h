@@ -120,7 +120,7 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * of the last call that the cap ended), "order_mode" (0 = hashed random order of
  * include/insider_perm.h, 1 = cyclic), "profile" (1 = time the statistics / solve kernels with HIP events),
  * "verbose" (1 = print the reference's per-checkpoint lines to stdout), "cd_variant" (elastic-net sweep kernel:
- * 0 = four genes per wavefront with the Gram matrix in registers [K <= 32; 32 < K <= 47 with the third coordinate slot's
+ * 0 = four genes per wavefront with the Gram matrix in registers [K <= 32; 32 < K <= 48 with the third coordinate slot's
  * columns in LDS], 2 = four genes per wavefront with the Gram matrix in LDS [K <= 48], 1 = one lane group per gene [also
  * what K > 48 takes]; all three follow the same sweep orders and agree to rounding), "row_merged" (1, default = masked
  * row update from per-(level, gene) weighted terms, 0 = from per-sample statistics; same results), "col_factored" (1,

@@ -1,5 +1,5 @@
 // insider_cd_reg.hpp — register-resident elastic-net coordinate descent for K <= 32: four genes per wavefront,
-// the Gram matrix in VGPRs, no LDS; and for 32 < K <= 47 with a third coordinate slot whose Gram columns live in LDS
+// the Gram matrix in VGPRs, no LDS; and for 32 < K <= 48 with a third coordinate slot whose Gram columns live in LDS
 // (REG_DEFINE_SWEEP3 below).
 //
 // strong_coordinate_descent's sweep loop (src/coordinate_descent.cpp:86-114) is a K-step sequential recurrence per
@@ -22,6 +22,7 @@
 namespace insider {
 
 constexpr int REG_ORDER_OFF = 128;   // byte offset of the block-offset dwords inside an order-table row
+constexpr int REG3_ORDER_OFF = 124;  // ... for 32 < K <= 48 (three slots): one dword earlier, so that 1 + 48 dwords fit the row
 static_assert(ORDER_ROW == 0x140, "the sweep prologue prefetches the next row at +0x140");
 constexpr int REG_BLOCK = INSIDER_REG_BLOCK;   // bytes between the code blocks of consecutive coordinates (see REG_BLOCK_HEAD)
 #define REG_STR_(x) #x
@@ -166,14 +167,15 @@ __device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][1
 #endif
 }
 
-// ---- 32 < K <= 47: three coordinate slots, the third slot's Gram columns in LDS (round 4) ---------------------------------
+// ---- 32 < K <= 48: three coordinate slots, the third slot's Gram columns in LDS (round 4) ---------------------------------
 // Lane i also owns coordinate 32 + i (i < KMAX - 32).  Columns i and 16 + i of the Gram matrix stay in VGPRs (4 KMAX of the 256
 // a wave may hold at two waves per SIMD); column 32 + i lives in an LDS panel of this wave — row k at byte k * PS, PS = (4 W + 1) * 8,
 // W = KMAX - 32 coordinates per gene, cell g * W + i for lane i < W of gene row g, and ONE zero cell (4 W) per row that every lane
 // without a third coordinate reads (so its y stays what it was).  Inside block k the panel row is static like the register
 // operands: `ds_read_b64 gc, la offset:k*PS` is the block's first instruction, the third DPP fmac waits for it behind the two
-// register ones.  Per step 7 vector + 1 LDS + 4 scalar instructions + the wait.  The successor list takes 48 dwords (dword 0 +
-// one per coordinate: K <= 47) in s[48:95]; the block table is longer than 4 KiB here and aligned to 8 KiB.
+// register ones.  Per step 7 vector + 1 LDS + 4 scalar instructions + the wait.  The successor list takes 49 dwords (dword 0 +
+// one per coordinate, K <= 48) in s[48:96], read from byte 124 of the order-table row (REG3_ORDER_OFF, k_order_table); the
+// block table is longer than 4 KiB here and aligned to 8 KiB.
 constexpr int reg3_w(int KMAX) { return KMAX - 32; }
 constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // panel row pitch in doubles
 #define REG3_HEAD(KK, HS, BS, IS, IT)                                        \
@@ -197,15 +199,17 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
     "s_load_dwordx16 s[48:63], %[tb], 0x0\n"       \
     "s_load_dwordx16 s[64:79], %[tb], 0x40\n"      \
     "s_load_dwordx16 s[80:95], %[tb], 0x80\n"      \
+    "s_load_dword s96, %[tb], 0xc0\n"              \
     "s_getpc_b64 s[98:99]\n"                       \
     "Lr%=:\n"                                      \
     "s_add_u32 s98, s98, Lc%=-Lr%=\n"              \
     "s_addc_u32 s99, s99, 0\n"                     \
     "s_mov_b32 vcc_hi, s99\n"                      \
     "s_waitcnt lgkmcnt(0)\n"                       \
-    "s_load_dword %[sk], %[tb], 0x140\n"           \
-    "s_load_dword %[p1], %[tb], 0x180\n"           \
-    "s_load_dword %[p2], %[tb], 0x1c0\n"           \
+    "s_load_dword %[sk], %[tb], 0x140\n"           /* the next row's list: four lines from byte 124 on */ \
+    "s_load_dword %[p1], %[tb], 0x144\n"           \
+    "s_load_dword %[p2], %[tb], 0x184\n"           \
+    "s_load_dword %[p3], %[tb], 0x1c4\n"           \
     "s_add_u32 vcc_lo, s48, s98\n"                 \
     "s_setpc_b64 vcc\n.p2align 13\n"              \
     "Lc%=:\n"
@@ -224,12 +228,13 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
     __device__ __forceinline__ void reg_sweep(RegState<3> &S, const double (&G)[2][KMAX], const uint32_t *tb, uint32_t la) \
     {                                                                                                                    \
         double dn, gc;                                                                                                   \
-        int sk, p1, p2;                                                                                                  \
+        int sk, p1, p2, p3;                                                                                              \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
         asm volatile(REG3_PROLOGUE REG_LIST_LO(REG3_BLOCK_LO) REG_HB_32(REG3_BLOCK_MID) REG_TB_##KMAX(REG3_BLOCK_TOP)    \
                          REG_EPILOGUE(KMAX)                                                                              \
                      : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [h2] "+v"(S.y[2]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), \
-                       [b2] "+v"(S.beta[2]), [dn] "=&v"(dn), [gc] "=&v"(gc), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2) \
+                       [b2] "+v"(S.beta[2]), [dn] "=&v"(dn), [gc] "=&v"(gc), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2),   \
+                       [p3] "=&s"(p3)                                                                                    \
                      : REG_LIST_LO(REG_GA) REG_HI_32(REG_GA) REG_T1_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_32(REG_GB)   \
                            REG_T1_##KMAX(REG_GB)[i0] "v"(S.tau[0]),                                                      \
                        [i1] "v"(S.tau[1]), [i2] "v"(S.tau[2]), [tb] "s"(tb), [lm] "s"(lm), [la] "v"(la)                  \
@@ -447,7 +452,7 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[reg_r
     asm volatile("" : "+s"(sweep), "+s"(stop));
 #endif
     // the table holds one period of the order sequence: sweep s reads row s mod INSIDER_PERM_PERIOD (include/insider_perm.h)
-    const uint32_t *tb0 = reinterpret_cast<const uint32_t *>(order + REG_ORDER_OFF);
+    const uint32_t *tb0 = reinterpret_cast<const uint32_t *>(order + (SLOTS == 3 ? REG3_ORDER_OFF : REG_ORDER_OFF));
     const uint32_t *tb = tb0 + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * (ORDER_ROW / 4);
     while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
@@ -818,7 +823,7 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
         case 30: { constexpr int SL_ = 2, KM_ = 30; CALL; } break; \
         default: { constexpr int SL_ = 2, KM_ = 32; CALL; } break; \
     }
-// 32 < K <= 47: three slots
+// 32 < K <= 48: three slots
 #define REG3_DISPATCH(K, CALL)                                     \
     switch (reg_kmax(K)) {                                         \
         case 36: { constexpr int SL_ = 3, KM_ = 36; CALL; } break; \

@@ -548,8 +548,8 @@ struct Timer {   // HIP-event pair around one launch on the library's stream (op
 // (h->order) when its solve is launched.  Two buffers: an outer iteration's table depends on (seed, iter) only, so the NEXT one
 // is built while the current solve runs — the sweep kernel leaves no room for other waves, so the builder runs in its tail,
 // on SIMDs that have already drained — instead of competing with the row phase.
-// 32 < K <= 47 with an l1 term: the register-resident kernel with its third slot's matrix columns in LDS (insider_cd_reg.hpp)
-static bool reg3_path(int K, double la, int variant) { return K > 32 && K <= 47 && la > 0.0 && variant == 0; }
+// 32 < K <= 48 with an l1 term: the register-resident kernel with its third slot's matrix columns in LDS (insider_cd_reg.hpp)
+static bool reg3_path(int K, double la, int variant) { return K > 32 && K <= 48 && la > 0.0 && variant == 0; }
 
 int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode, double la,
                        hipStream_t stream = nullptr, int slot = 0)
@@ -2414,11 +2414,11 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
                                            nprob, cd, db, ds));
     } else if (K <= 16) hipLaunchKernelGGL((k_cd_batch<16, 4>), dim3(cdiv(nprob, 16)), dim3(256), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32) hipLaunchKernelGGL((k_cd_batch<32, 2>), dim3(cdiv(nprob, 4)), dim3(128), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
-    else if (reg3) {   // 32 < K <= 47: register-resident with the third slot's matrix columns in LDS
+    else if (reg3) {   // 32 < K <= 48: register-resident with the third slot's matrix columns in LDS
         REG3_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0, dG, dq, dw, K,
                                             nprob, cd, db, ds));
     }
-    else if (K <= 48 && variant != 1) {   // K = 48, lambda alpha = 0 or INSIDER_CD_VARIANT=2: the LDS-resident row16 solver (=1: one problem per wavefront)
+    else if (K <= 48 && variant != 1) {   // lambda alpha = 0 or INSIDER_CD_VARIANT=2: the LDS-resident row16 solver (=1: one problem per wavefront)
         if (int rl = r16_wide_lds(r16_bytes)) return rl;
         hipLaunchKernelGGL((k_cd_batch_r16<3>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
     }

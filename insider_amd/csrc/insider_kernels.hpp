@@ -371,8 +371,8 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
 // order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
 // the row16 kernel; K > 32: 64 of them, bytes [64, 192)); bytes [128, 320), K <= 32: 48 uint32, the code-block offsets of the register-resident kernel
 // (insider_cd_reg.hpp) as a successor list: dword 0 = INSIDER_REG_BLOCK * (first coordinate of the sweep), dword 1 + k = INSIDER_REG_BLOCK * (the
-// coordinate visited after k), exit_block for the last one and for k >= K.  One thread per (sweep, coordinate): rank
-// by counting.
+// coordinate visited after k), exit_block for the last one and for k >= K; 32 < K <= 48 on that kernel (wide_rows = 0): the same
+// list from byte 124 on (30 row offsets).  One thread per (sweep, coordinate): rank by counting.
 __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
                                                      int pitch_bytes, int exit_block, int wide_rows, uint8_t *__restrict__ order)
 {
@@ -396,19 +396,22 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     if (!live) return;
     uint32_t *blk = reinterpret_cast<uint32_t *>(row + 128);
     // wide rows (K > 32 on the row16 kernel with three or four slots): 64 row offsets in bytes [64, 192) and no successor list,
-    // which shares those bytes; K <= 47 on the register-resident kernel: the list (1 + K <= 48 dwords), 32 row offsets
+    // which shares those bytes; 32 < K <= 48 on the register-resident kernel: the list (1 + K <= 49 dwords from byte 124), 30 row offsets
     const bool wide = wide_rows != 0;
+    // narrow rows for K > 32 (three-slot register kernel, K <= 48) hold the list one dword earlier — first block at byte 124,
+    // successor of coordinate k at 128 + 4 k — so that 1 + 48 dwords fit the row; the kernel loads from byte 124 there
+    const int shift = K > 32 ? 1 : 0;
     if (l >= K) {
         row[l] = 0;
-        if (l < 32 || wide) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
-        if (l < 47 && !wide) blk[1 + l] = (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
+        if (l < (shift ? 30 : 32) || wide) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
+        if (l < 47 + shift && !wide) blk[1 + l - shift] = (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
         return;
     }
     row[rank] = (uint8_t)l;
-    if (rank < 32 || wide) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
+    if (rank < (shift ? 30 : 32) || wide) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
     if (wide) return;
-    if (l < 47) blk[1 + l] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * (uint32_t)INSIDER_REG_BLOCK : (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
-    if (rank == 0) blk[0] = (uint32_t)l * (uint32_t)INSIDER_REG_BLOCK;
+    if (l < 47 + shift) blk[1 + l - shift] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * (uint32_t)INSIDER_REG_BLOCK : (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
+    if (rank == 0) blk[0 - shift] = (uint32_t)l * (uint32_t)INSIDER_REG_BLOCK;
 }
 
 // ---------------------------------------------------------------------------------------------

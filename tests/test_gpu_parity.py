@@ -135,9 +135,9 @@ def test_strong_cd_matches_oracle(oracle, K, lam, alpha, tol):
         assert same_sweeps >= B - 2
 
 
-@pytest.mark.parametrize("K", [2, 3, 8, 15, 16] + list(range(17, 33)) + [33, 35, 36, 37, 40, 41, 43, 44, 45, 47])   # (> 32: three slots, the third in LDS)
+@pytest.mark.parametrize("K", [2, 3, 8, 15, 16] + list(range(17, 33)) + [33, 35, 36, 37, 40, 41, 43, 44, 45, 47, 48])   # (> 32: three slots, the third in LDS)
 def test_strong_cd_every_register_kernel_instantiation(oracle, K):
-    """K <= 32 runs the register-resident kernel, instantiated per even K above 16 (insider_cd_reg.hpp), 32 < K <= 47 its
+    """K <= 32 runs the register-resident kernel, instantiated per even K above 16 (insider_cd_reg.hpp), 32 < K <= 48 its
     three-slot form (third slot's Gram columns in LDS; KMAX = 36, 40, 44, 48): every instantiation against the oracle,
     with screened-out coordinates (strong rule) and a partial last wave."""
     rng = np.random.default_rng(100 + K)
@@ -159,7 +159,7 @@ def test_strong_cd_every_register_kernel_instantiation(oracle, K):
         assert np.array_equal(ob == 0, beta[b] == 0)          # identical sparsity pattern
 
 
-@pytest.mark.parametrize("K", [16, 17, 19, 21, 22, 24, 25, 28, 30, 31, 33, 36, 38, 40, 42, 44, 46, 47])
+@pytest.mark.parametrize("K", [16, 17, 19, 21, 22, 24, 25, 28, 30, 31, 33, 36, 38, 40, 42, 44, 46, 47, 48])
 def test_optimize_column_kernel_instantiations(oracle, K):
     w = workloads.small(K=K, n=90, p=75, seed=K, f=0.2)
     A, C = _cp(w)
@@ -316,7 +316,7 @@ def test_optimize_options(oracle, opts):
     assert relerr(got["column_factor"], ref["column_factor"]) < 1e-7
 
 
-@pytest.mark.parametrize("K,limits", [(12, (32, 2)), (30, (32, 3)), (20, (64, 2)), (7, (32, 16)), (40, (32, 2)), (47, (64, 3))])
+@pytest.mark.parametrize("K,limits", [(12, (32, 2)), (30, (32, 3)), (20, (64, 2)), (7, (32, 16)), (40, (32, 2)), (48, (64, 3))])
 def test_multipass_column_solve_is_bit_identical(oracle, K, limits):
     """Cold outer iterations solve in passes (options cd_pass1 / cd_pass_ratio / cd_cold_iters, insider_cd_reg.hpp): a limited
     pass stops at a sweep index, the unfinished genes are re-packed by estimated remaining length and continued from their

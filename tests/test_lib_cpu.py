@@ -161,11 +161,11 @@ def test_sweep_kernels_do_not_spill(tmp_path, lib):
         if kmax <= 30:
             assert not scratch, (head, scratch[:4])
         # the sweep's prologue: its table loads end with the s_getpc_b64 that anchors the code-block table
-        sites = [i - 3 for i, (_, t, _r) in enumerate(ins) if t.startswith("s_getpc_b64 s[98:99]")]
+        sites = [i - (4 if kmax > 32 else 3) for i, (_, t, _r) in enumerate(ins) if t.startswith("s_getpc_b64 s[98:99]")]
         if "k_cd_cols_reg" in head and "ELb0E" in head:
             assert not sites, head                 # the evaluation kernels have no sweep loop
             continue
-        first = "s_load_dwordx16 s[48:63]" if kmax > 32 else "s_load_dwordx16 s[64:79]"   # (three slots: 48 list dwords)
+        first = "s_load_dwordx16 s[48:63]" if kmax > 32 else "s_load_dwordx16 s[64:79]"   # (three slots: 49 list dwords, four loads)
         assert len(sites) == 1 and ins[sites[0]][1].startswith(first), (head, len(sites))
         a0 = ins[sites[0]][0]
         # the loop's back edge: the first branch after the sweep whose target lies at or shortly before the sweep's first load

@@ -4,7 +4,7 @@
 R=$(dirname $(dirname $(readlink -f $0)))
 S=$R/gpurun_out/r04; D=$R/profiles/r04
 mkdir -p $D
-for f in bench_c1 bench_c2 bench_c3 bench_c3_s20w5 bench_c4 bench_c5 bench_c3_K32 bench_c3_K40 bench_c3_K63 bench_c3_ctns2 grid_c1_k4 grid_c2_k4 grid_c3_k2 prof_c3 prof_c5; do
+for f in bench_c1 bench_c2 bench_c3 bench_c3_s20w5 bench_c4 bench_c5 bench_c3_K32 bench_c3_K33 bench_c3_K36 bench_c3_K40 bench_c3_K44 bench_c3_K47 bench_c3_K48 bench_c3_K63 bench_c3_ctns2 grid_c1_k4 grid_c2_k4 grid_c3_k2 prof_c3 prof_c5; do
   [ -f $S/$f.json ] && cp $S/$f.json $D/
 done
 cp $(ls -t $S/prof_c3/*/*kernel_stats.csv | head -1) $D/c3_kernel_stats.csv

@@ -26,7 +26,7 @@ done
 $B --grid --concurrent 2 --no-cpu-baseline > $OUT/grid_c3_k2.json 2> $OUT/grid_c3_k2.err || exit 1
 echo "grids done"
 # K range at c3's shape; continuous covariates at c3's size
-for KK in 32 33 40 48 63; do
+for KK in 32 33 36 40 44 47 48 63; do
   $B --latent $KK --steps 11 --no-cpu-baseline > $OUT/bench_c3_K$KK.json 2> $OUT/bench_c3_K$KK.err || exit 1
 done
 $B --ctns 2 --no-cpu-baseline > $OUT/bench_c3_ctns2.json 2> $OUT/bench_c3_ctns2.err || exit 1
