@@ -430,12 +430,14 @@ def main():
         # sources they were taken on
         from insider_amd import _lib as ilib
         lib_sha = ilib.library_source_sha()           # what the loaded binary says it was compiled from
+        # (PMC figures belong to one problem: a line with --latent / --ctns looks for its own entry, e.g. "c3_K40")
+        pmc_key = name + (f"_K{K}" if args.latent > 0 else "") + (f"_ctns{args.ctns}" if args.ctns > 0 else "")
         traffic, tnote = {}, "no profiles/traffic.json entry for this workload"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get(name, {})
+                ent = tj.get(pmc_key, {})
                 if ent and world == 1:
                     # valid only for the library it was measured on: compared with the hash the LOADED library reports
                     same = tj.get("source_sha") == lib_sha
@@ -455,9 +457,9 @@ def main():
         if os.path.exists(ipath) and world == 1:
             try:
                 ij = json.load(open(ipath))
-                if name in ij:
+                if pmc_key in ij:
                     if ij.get("source_sha") == lib_sha:
-                        issue = ij[name]
+                        issue = ij[pmc_key]
                         inote = f"rocprofv3 --pmc SQ_* passes ({ij.get('command', '?')}), source_sha {ij.get('source_sha')} = the library that ran here"
                     else:
                         inote = f"profiles/issue.json was taken on source_sha {ij.get('source_sha')}, not on the library that ran here ({lib_sha}): withheld"
