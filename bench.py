@@ -533,8 +533,9 @@ def main():
                           # 1024 SIMDs, at the clock the part held during the counter passes (GRBM_GUI_ACTIVE / 8 / kernel time;
                           # 2.4 GHz nominal when no counters are on file): how close the kernel is to ITS ceiling, not a hardware
                           # roofline.  valu_busy_measured = SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles of the kernel (rocprofv3 --pmc)
-                          "valu_issue_model_updates_per_s": 1024 * 4 * cd_clock / (6 * 4),
-                          "valu_issue_model_frac": cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * cd_clock / (6 * 4)),
+                          # vector instructions per 4-gene step: 6 (K <= 32), 7 with the third slot (32 < K <= 48); the model does not apply beyond
+                          "valu_issue_model_updates_per_s": (1024 * 4 * cd_clock / ((6 if K <= 32 else 7) * 4)) if K <= 48 else None,
+                          "valu_issue_model_frac": (cd_updates / max(prof["cd_ms"] * 1e-3, 1e-9) / (1024 * 4 * cd_clock / ((6 if K <= 32 else 7) * 4))) if K <= 48 else None,
                           "valu_issue_model_clock_GHz": cd_clock / 1e9,
                           "valu_busy_measured": cd_issue.get("valu_busy_of_resident_simd_time"),
                           "issue_counters": cd_issue or None, "issue_counters_note": inote,
