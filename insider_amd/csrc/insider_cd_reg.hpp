@@ -174,12 +174,14 @@ __device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][1
 // without a third coordinate reads (so its y stays what it was).  Inside block k the panel row is static like the register
 // operands: `ds_read_b64 gc, la offset:k*PS` is the block's first instruction, the third DPP fmac waits for it behind the two
 // register ones.  Per step 7 vector + 1 LDS + 4 scalar instructions + the wait.  The successor list takes 49 dwords (dword 0 +
-// one per coordinate, K <= 48) in s[48:96], read from byte 124 of the order-table row (REG3_ORDER_OFF, k_order_table); the
-// block table is longer than 4 KiB here and aligned to 8 KiB.
+// one per coordinate, K <= 48) in s[48:96], read from byte 124 of the order-table row (REG3_ORDER_OFF, k_order_table).  A block
+// is exactly INSIDER_REG3_BLOCK = 80 bytes long and the blocks are packed (.org fails the build if one outgrows its slot): the
+// table of 49 blocks stays below 4 KiB, so the shared-high-word argument of the two-slot kernel holds with page alignment alone.
 constexpr int reg3_w(int KMAX) { return KMAX - 32; }
 constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // panel row pitch in doubles
+#define REG3_ORG(KK) ".org Lc%= + " REG_STR(INSIDER_REG3_BLOCK) "*" #KK "\n"
 #define REG3_HEAD(KK, HS, BS, IS, IT)                                        \
-    REG_ORG(KK)                                                              \
+    REG3_ORG(KK)                                                             \
     "ds_read_b64 %[gc], %[la] offset:(" #KK "*" REG3_PS_STR ")\n"            \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                                      \
     "v_max_f64 %[dn], %[" HS "], %[" HS "] clamp\n"                          \
@@ -211,7 +213,7 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
     "s_load_dword %[p2], %[tb], 0x184\n"           \
     "s_load_dword %[p3], %[tb], 0x1c4\n"           \
     "s_add_u32 vcc_lo, s48, s98\n"                 \
-    "s_setpc_b64 vcc\n.p2align 13\n"              \
+    "s_setpc_b64 vcc\n.p2align 12\n"              \
     "Lc%=:\n"
 #define REG3_CLOBBERS REG_CLOBBERS, "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
 #define REG_T1_36(F) F(32) F(33) F(34) F(35)
@@ -231,7 +233,7 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
         int sk, p1, p2, p3;                                                                                              \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
         asm volatile(REG3_PROLOGUE REG_LIST_LO(REG3_BLOCK_LO) REG_HB_32(REG3_BLOCK_MID) REG_TB_##KMAX(REG3_BLOCK_TOP)    \
-                         REG_EPILOGUE(KMAX)                                                                              \
+                         REG3_ORG(KMAX) " s_waitcnt lgkmcnt(0)\n"   /* exit block */                                    \
                      : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [h2] "+v"(S.y[2]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), \
                        [b2] "+v"(S.beta[2]), [dn] "=&v"(dn), [gc] "=&v"(gc), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2),   \
                        [p3] "=&s"(p3)                                                                                    \

@@ -366,6 +366,7 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
 #ifndef INSIDER_REG_BLOCK
 #define INSIDER_REG_BLOCK 96
 #endif
+#define INSIDER_REG3_BLOCK 80   // ... in its three-slot form (32 < K <= 48): the blocks are exactly this long and packed, 49 of them stay below 4 KiB
 
 // Order table, one row of ORDER_ROW bytes per sweep s < nsweeps: bytes [0, 64): the K coordinates in ascending key
 // order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
@@ -401,17 +402,18 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     // narrow rows for K > 32 (three-slot register kernel, K <= 48) hold the list one dword earlier — first block at byte 124,
     // successor of coordinate k at 128 + 4 k — so that 1 + 48 dwords fit the row; the kernel loads from byte 124 there
     const int shift = K > 32 ? 1 : 0;
+    const uint32_t bb = K > 32 ? (uint32_t)INSIDER_REG3_BLOCK : (uint32_t)INSIDER_REG_BLOCK;   // bytes per code block
     if (l >= K) {
         row[l] = 0;
         if (l < (shift ? 30 : 32) || wide) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
-        if (l < 47 + shift && !wide) blk[1 + l - shift] = (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
+        if (l < 47 + shift && !wide) blk[1 + l - shift] = (uint32_t)exit_block * bb;
         return;
     }
     row[rank] = (uint8_t)l;
     if (rank < (shift ? 30 : 32) || wide) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
     if (wide) return;
-    if (l < 47 + shift) blk[1 + l - shift] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * (uint32_t)INSIDER_REG_BLOCK : (uint32_t)exit_block * (uint32_t)INSIDER_REG_BLOCK;
-    if (rank == 0) blk[0 - shift] = (uint32_t)l * (uint32_t)INSIDER_REG_BLOCK;
+    if (l < 47 + shift) blk[1 + l - shift] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * bb : (uint32_t)exit_block * bb;
+    if (rank == 0) blk[0 - shift] = (uint32_t)l * bb;
 }
 
 // ---------------------------------------------------------------------------------------------
