@@ -155,6 +155,7 @@ struct insider_hip_handle {
     double *Astack = nullptr, *R = nullptr, *C = nullptr, *RtR = nullptr, *CCt = nullptr, *Qfull = nullptr, *SC = nullptr;
     double *stat = nullptr, *stat_col = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
     double *lvl_sum = nullptr;
+    double *lvl_zero = nullptr;   // max_L x (STAT + 2 KP + 2) zeros: the (empty) held-out sums of the unmasked row update (unmasked_fused)
     double *Strain = nullptr;         // per-level sums of X over TRAIN entries (p x SLP), once per data set
     double *Sheld = nullptr;          // S - Strain: per-level sums over the held-out entries
     double *Qheld = nullptr;          // p x KP workspace: sum_l A_l' Sheld[j][l]
@@ -244,7 +245,7 @@ std::vector<void **> workspace_slots(insider_hip_handle *h)
     std::vector<void **> v;
     auto add = [&v](auto &ptr) { v.push_back(reinterpret_cast<void **>(&ptr)); };
     add(h->Astack); add(h->R); add(h->C); add(h->RtR); add(h->CCt); add(h->Qfull); add(h->SC); add(h->stat); add(h->stat_col);
-    add(h->gram_part); add(h->sc_part); add(h->gram_part2); add(h->sc_part2); add(h->lvl_part); add(h->lvl_sum); add(h->lvl_sum_all);
+    add(h->gram_part); add(h->sc_part); add(h->gram_part2); add(h->sc_part2); add(h->lvl_part); add(h->lvl_sum); add(h->lvl_zero); add(h->lvl_sum_all);
     add(h->U); add(h->Ylvl); add(h->wpart); add(h->Vlev); add(h->Qheld); add(h->eq); add(h->sse_train); add(h->sse_test); add(h->b2);
     add(h->b1); add(h->loss_buf); add(h->stage); add(h->wg_part); add(h->wg_pair); add(h->sweeps); add(h->sweep_key); add(h->failflag);
     add(h->sweep_total); add(h->order_buf[0]); add(h->order_buf[1]); add(h->gene_perm); add(h->sched_cnt[0]); add(h->sched_cnt[1]);
@@ -337,6 +338,8 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->sc_part, (size_t)h->sc_blocks * h->SL * KP))) return rc;
     if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP + 2)))) return rc;
     if ((rc = dmalloc(&h->lvl_sum, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2)))) return rc;
+    if ((rc = dmalloc(&h->lvl_zero, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2)))) return rc;
+    HIPCHECK(hipMemsetAsync(h->lvl_zero, 0, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2) * sizeof(double), h->stream));
     if (h->merged) {
         // k_wgemm (weighted SYRK as a GEMM over genes): partial sums per gene slab, and the packed pair index -> (a, b) table
         size_t wg_len = 0;
@@ -987,6 +990,15 @@ bool use_merged(const insider_hip_handle *h, int masked)
     return 1.1 * merged_us < old_us;
 }
 
+// tuning = 0 (src/optimize.cpp:178-191): XtX_l = |l| CC' + lambda I and Xty_l = (S C')[l] - CC' sum_{r in l} s_r are the merged
+// update's equations with EMPTY held-out sums, and sum_{r in l} s_r comes from the level-pair sample counts: one launch per
+// covariate (k_level_merged on an all-zero record) instead of five over the samples, and R is rebuilt once per outer iteration.
+// What it buys is launch latency: on small data a long unmasked fit (the reference's fit() default) is a chain of ~5 us kernels.
+bool unmasked_fused(const insider_hip_handle *h, int masked)
+{
+    return !masked && h->merged && h->row_merged && h->row_fused && h->m == 0 && h->lvl_zero;
+}
+
 // V = C A' for the stacked levels [q_begin, q_end) (all of them once per outer iteration, then the updated covariate's)
 int launch_gene_v(insider_hip_handle *h, int q_begin, int q_end)
 {
@@ -1217,6 +1229,17 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
                 ra.part = rec;
                 hipLaunchKernelGGL((k_level_reduce<NB_>), dim3(L), dim3(64), 0, h->stream, ra);
             }
+        });
+    } else if (!cont && unmasked_fused(h, masked)) {
+        const int L = ct.L, KP = h->KP;
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            fused_solve = h->world <= 1 && !h->force_allreduce && NB_ <= 2;
+            hipLaunchKernelGGL((k_level_merged<NB_>), dim3(L), dim3(256), 0, h->stream, (const double *)h->lvl_zero,
+                               (const double *)h->lvl_zero, 0, (const double *)ct.paircnt, h->SL, (const double *)h->Astack,
+                               (const int *)(h->lvl_count_all + h->lvl_off[i]), (const double *)h->CCt,
+                               (const double *)(h->SC + (size_t)row0 * KP), L, h->K, lambda1, fused_solve ? 1 : 0, h->eq,
+                               h->Astack + (size_t)row0 * KP, h->failflag);
         });
     } else {
         NB_DISPATCH(h->NB, {
@@ -2145,7 +2168,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
         if (use_merged(h, masked) && h->row_head) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_head, 0));   // launch_wsyrk_side
         const bool cont_follow = inc_continuous && h->m > 0;
         for (int i = 0; i < h->c; ++i) {
-            const bool need_R = !use_merged(h, masked) || (i + 1 == h->c && !cont_follow);
+            const bool need_R = !(use_merged(h, masked) || unmasked_fused(h, masked)) || (i + 1 == h->c && !cont_follow);
             if ((rc = row_update(h, i, -1, masked, lambda1, need_R))) return rc;                // :339
             if (use_merged(h, masked) && (i + 1 < h->c || cont_follow))   // (the continuous columns read every categorical column of V)
                 if ((rc = launch_gene_v(h, h->lvl_off[i], h->lvl_off[i + 1]))) return rc;

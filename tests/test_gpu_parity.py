@@ -398,6 +398,32 @@ def test_fused_level_kernel_is_bit_identical(K, levels):
         assert np.array_equal(runs[0]["row_matrices"][f"factor{i}"], runs[1]["row_matrices"][f"factor{i}"])
 
 
+@pytest.mark.parametrize("K,levels,alpha", [(9, (7, 4), 0.4), (23, (2, 16, 8, 107), 0.4), (30, (12, 5, 3), 0.0), (40, (6, 5), 0.3)])
+def test_unmasked_row_update_in_one_launch_per_covariate(oracle, K, levels, alpha):
+    """tuning = 0 (src/optimize.cpp:178-191): the level equations are the merged update's with empty held-out sums, so the
+    unmasked row update is one k_level_merged launch per covariate on an all-zero record (sum_{r in l} s_r from the level-pair
+    sample counts), with R rebuilt once per outer iteration, instead of five launches over the samples per covariate (option
+    row_fused = 0 keeps those).  Same equations, sum_{r in l} s_r in another order: the fits agree to rounding, and both agree
+    with the oracle."""
+    w = workloads.small(K=K, n=330, p=240, level_counts=levels, f=0.2, seed=30 + K)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    runs = []
+    for fused in (0, 1):
+        ds.set_option("row_fused", fused)
+        runs.append(ds.optimize(*_cp(w), w.K, w.lam, w.lam, alpha, tuning=0, max_iter=6, seed=5))
+    ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, alpha, tuning=0,
+                          max_iter=6, seed=5)
+    for r in runs:
+        assert relerr(r["column_factor"], ref["column_factor"]) < 1e-6
+        assert np.allclose(r["traj"][:, 3:8], ref["traj"][:, 3:8], rtol=1e-9, atol=0)
+        for i in range(len(w.A0)):
+            assert relerr(r["row_matrices"][f"factor{i}"], ref["row_matrices"][i]) < 1e-6
+    assert relerr(runs[0]["column_factor"], runs[1]["column_factor"]) < 1e-9
+    for i in range(len(w.A0)):
+        assert relerr(runs[0]["row_matrices"][f"factor{i}"], runs[1]["row_matrices"][f"factor{i}"]) < 1e-9
+
+
 @pytest.mark.parametrize("K,levels", [(7, (60, 3)), (20, (100, 10)), (30, (130, 7, 2)), (33, (64, 5))])
 def test_level_gram_as_gemm_matches_the_rank_one_form(oracle, K, levels):
     """Covariates with many levels get their per-level weighted Gram sums sum_j n_jl c_j c_j' from ONE GEMM over genes
