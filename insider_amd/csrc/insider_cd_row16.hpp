@@ -1,8 +1,9 @@
 // insider_cd_row16.hpp — "row16" elastic-net coordinate descent, four genes per wavefront, Gram matrix in LDS: the cross-check
-// of the register-resident kernel for K <= 32 (SLOTS = 1, 2) and, since round 4, THE sweep kernel for 32 < K <= 48 (SLOTS = 3),
-// where the Gram matrix does not fit registers and two waves' blocks still fit a CU's LDS (beyond: k_cd_cols<64, 1>).
-// (Also measured there and dropped: the register kernel's scaled state — soft threshold as the output clamp, increments through a
-// DPP fmac — with the LDS reads issued a step ahead: +4 %; the kernel is bound by its occupancy, two waves per CU, not by the chain.)
+// of the register-resident kernel (option cd_variant = 2) for K <= 32 (SLOTS = 1, 2) and for 32 < K <= 48 (SLOTS = 3: two waves'
+// blocks still fit a CU's LDS), the solver for 32 < K <= 48 without an l1 term, and the evaluation pass (loss statistics) of the
+// three-slot register kernel.  (Mid-round 4 it was THE sweep kernel for 32 < K <= 48: 16 outer-iterations/s at K = 40, c3's shape;
+// the register kernel's three-slot form, insider_cd_reg.hpp, runs 76.  Also measured here and dropped: the register kernel's
+// scaled state with the LDS reads issued a step ahead: +4 %; this kernel is bound by its occupancy, two waves per CU.)
 //
 // The sweep loop of strong_coordinate_descent (src/coordinate_descent.cpp:86-114) is a K-step sequential
 // recurrence per gene and, at BASELINE's tolerances, runs for hundreds to thousands of sweeps: it is issue-bound
@@ -279,7 +280,7 @@ __device__ __forceinline__ int cd_row16(double *lds, int K, const double (&q)[SL
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel: column update with the row16 solver (K <= 32); same contract as k_cd_cols
+// Kernel: column update with the row16 solver (K <= 48); same contract as k_cd_cols
 // ---------------------------------------------------------------------------------------------
 template <int SLOTS>
 __global__ void __launch_bounds__(64) k_cd_cols_r16(ColArgs a)

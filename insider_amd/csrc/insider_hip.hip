@@ -897,9 +897,9 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
         else if (h->K <= 16) hipLaunchKernelGGL((k_cd_cols<16, 4>), dim3(cdiv(h->p, 16)), dim3(256), 0, h->stream, a);
         else if (h->K <= 32) hipLaunchKernelGGL((k_cd_cols<32, 2>), dim3(cdiv(h->p, 4)), dim3(128), 0, h->stream, a);
         else if (h->cd_variant != 1 && h->K <= 48) {
-            // 32 < K <= 48: four genes per wavefront with the Gram matrices in LDS (row16 kernel, three coordinate slots per lane;
-            // round 4: 1.9 x the one-gene-per-wavefront kernel at K = 40).  Beyond 48 a CU's LDS holds one such wave and the
-            // kernel below is faster; it also stays as cd_variant = 1 (cross-check)
+            // 32 < K <= 48 when the register-resident kernel's three-slot form does not apply (cd_variant = 2, or no l1 term): four genes
+            // per wavefront with the whole Gram matrices in LDS (row16 kernel, three coordinate slots per lane).  Beyond 48 a CU's LDS
+            // holds one such wave and the kernel below is faster; it also stays as cd_variant = 1 (cross-check)
             if (int rl = r16_wide_lds(r16_bytes)) return rl;
             hipLaunchKernelGGL((k_cd_cols_r16<3>), dim3(cdiv(h->p, 4)), dim3(64), r16_bytes, h->stream, a);
         }
@@ -2092,7 +2092,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
     else if (s == "cd_split") h->cd_split = (int)value;           // 2 = steady-state column steps run split (long genes first, on their own stream); 0 (default) = never (measured: no gain, see use_split)
     else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)
-    else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave, K <= 32), 1 = group kernel, 2 = row16 (LDS)
+    else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave; K <= 32, and 32 < K <= 48 with the third slot's columns in LDS), 1 = group kernel, 2 = row16 (LDS, K <= 48)
     else return fail(INSIDER_ERR_ARG, "unknown option " + s);
     return INSIDER_OK;
 }
