@@ -132,7 +132,9 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * launch order, at most cd_long_frac [0.03] of the genes — get their statistics and their solve on a stream of their own, ahead
  * of the others' statistics; bit-identical results; 0 [default] = off: measured, it does not shorten the step),
  * "row_fused" (1, default = the merged row update forms a level's equations and
- * solve in one launch), "row_gemm" / "row_gemm_waves" (1, default = the per-level weighted Gram sums of a covariate with >= 49
+ * solve in one launch; with tuning = 0 the whole unmasked row update of a covariate is that one launch; 0 = separate launches),
+ * "list_fine" (1, default = the per-entry statistics kernel uses the 4x4x4 form of the f64 matrix instruction for 16 <= K <= 31
+ * [fewer wasted outputs than 16 x 16 blocks], 0 = the 16x16x4 form; same sums in another order), "row_gemm" / "row_gemm_waves" (1, default = the per-level weighted Gram sums of a covariate with >= 49
  * levels come from one GEMM over genes, cut into row_gemm_waves [1024] waves; 0 = one weighted rank-one update per (level, gene);
  * same sums in another order, results agree to rounding), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
  * cd_cold_iters outer iterations of a call [default 3]: the register-resident sweep kernel stops at sweep cd_pass1 [64; 0 = one

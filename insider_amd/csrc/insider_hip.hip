@@ -155,6 +155,7 @@ struct insider_hip_handle {
     double *Astack = nullptr, *R = nullptr, *C = nullptr, *RtR = nullptr, *CCt = nullptr, *Qfull = nullptr, *SC = nullptr;
     double *stat = nullptr, *stat_col = nullptr, *gram_part = nullptr, *sc_part = nullptr, *lvl_part = nullptr, *eq = nullptr;
     double *lvl_sum = nullptr;
+    double *fperm = nullptr;      // max(n, p) x KP: the factor rows in k_tile_perm's order (k_list_stats4)
     double *lvl_zero = nullptr;   // max_L x (STAT + 2 KP + 2) zeros: the (empty) held-out sums of the unmasked row update (unmasked_fused)
     double *Strain = nullptr;         // per-level sums of X over TRAIN entries (p x SLP), once per data set
     double *Sheld = nullptr;          // S - Strain: per-level sums over the held-out entries
@@ -209,6 +210,7 @@ struct insider_hip_handle {
     double *cd_hsave = nullptr, *cd_isave = nullptr;
     uint32_t *cd_pass_slot = nullptr;
     int *cd_pass_perm[2] = {nullptr, nullptr}, *cd_pass_cnt = nullptr;   // cd_pass_cnt: CD_BUCKETS counters + 2 list lengths
+    int list_fine = 1;   // option "list_fine": 1 (default) = k_list_stats4 (4x4x4 matrix instruction) where it applies, 0 = k_list_stats
     int cd_cold_iters = 3, cd_pass_first = 64, cd_pass_ratio = 4;   // options "cd_cold_iters", "cd_pass1" (0 = single pass), "cd_pass_ratio"
     // longest-first gene orders of outer iterations 0..2 of the previous optimize() on this handle: the early iterations
     // of the next call (tune()'s next grid point) have similar per-gene sweep counts, its later ones do not
@@ -245,7 +247,7 @@ std::vector<void **> workspace_slots(insider_hip_handle *h)
     std::vector<void **> v;
     auto add = [&v](auto &ptr) { v.push_back(reinterpret_cast<void **>(&ptr)); };
     add(h->Astack); add(h->R); add(h->C); add(h->RtR); add(h->CCt); add(h->Qfull); add(h->SC); add(h->stat); add(h->stat_col);
-    add(h->gram_part); add(h->sc_part); add(h->gram_part2); add(h->sc_part2); add(h->lvl_part); add(h->lvl_sum); add(h->lvl_zero); add(h->lvl_sum_all);
+    add(h->gram_part); add(h->sc_part); add(h->gram_part2); add(h->sc_part2); add(h->lvl_part); add(h->lvl_sum); add(h->lvl_zero); add(h->fperm); add(h->lvl_sum_all);
     add(h->U); add(h->Ylvl); add(h->wpart); add(h->Vlev); add(h->Qheld); add(h->eq); add(h->sse_train); add(h->sse_test); add(h->b2);
     add(h->b1); add(h->loss_buf); add(h->stage); add(h->wg_part); add(h->wg_pair); add(h->sweeps); add(h->sweep_key); add(h->failflag);
     add(h->sweep_total); add(h->order_buf[0]); add(h->order_buf[1]); add(h->gene_perm); add(h->sched_cnt[0]); add(h->sched_cnt[1]);
@@ -338,6 +340,8 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->sc_part, (size_t)h->sc_blocks * h->SL * KP))) return rc;
     if ((rc = dmalloc(&h->lvl_part, (size_t)h->max_chunks * (STAT + 2 * KP + 2)))) return rc;
     if ((rc = dmalloc(&h->lvl_sum, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2)))) return rc;
+    if (NB == 2 && K >= 16)   // (the statistics kernels that read it exist for 16 <= K <= 31)
+        if ((rc = dmalloc(&h->fperm, (size_t)std::max(h->n, h->p) * KP))) return rc;
     if ((rc = dmalloc(&h->lvl_zero, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2)))) return rc;
     HIPCHECK(hipMemsetAsync(h->lvl_zero, 0, (size_t)std::max(h->max_L, 1) * (STAT + 2 * KP + 2) * sizeof(double), h->stream));
     if (h->merged) {
@@ -434,6 +438,24 @@ int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *
     const int *lidx = cols ? h->col_idx : h->row_idx;
     const double *lval = cols ? h->col_val : h->row_val;
     const int64_t items = (int64_t)units * nseg;
+    // 16 <= K <= 31: the 4x4x4 form of the matrix instruction (fewer wasted outputs: 28 tiles instead of 3 blocks at K = 25)
+    const int NT = (h->K + 4) / 4;
+    if (h->list_fine && h->NB == 2 && NT >= 5 && NT <= 8 && h->fperm) {
+        // the rows in the tile-pair order the kernel's 16-byte loads want (a copy: every other consumer keeps F's order)
+        hipLaunchKernelGGL(k_tile_perm, dim3(cdiv(f_rows * h->KP, 256)), dim3(256), 0, h->stream, F, f_rows, h->KP, h->fperm);
+#define LS4(NT_)                                                                                                               \
+    hipLaunchKernelGGL((k_list_stats4<2, NT_, 4>), dim3(cdiv(items, 4)), dim3(256), 0, h->stream, ptr, lidx, lval, units, nseg,   \
+                       (const double *)h->fperm, f_rows, stat, base, h->K)
+        switch (NT) {
+            case 5: LS4(5); break;
+            case 6: LS4(6); break;
+            case 7: LS4(7); break;
+            default: LS4(8); break;
+        }
+#undef LS4
+        KCHECK();
+        return INSIDER_OK;
+    }
     NB_DISPATCH(h->NB, hipLaunchKernelGGL((k_list_stats<NB_, WPB_>), dim3(cdiv(items, WPB_)), dim3(WPB_ * 64), 0,
                                            h->stream, ptr, lidx, lval, units, nseg, F, f_rows, stat, base, h->K));
     KCHECK();
@@ -2090,6 +2112,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_cold_iters") h->cd_cold_iters = (int)value;   // outer iterations 0 .. value-1 of a call solve in passes
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
+    else if (s == "list_fine") h->list_fine = (int)value;       // 1 (default) = per-entry statistics on v_mfma_f64_4x4x4 for 16 <= K <= 31, 0 = on 16x16x4
     else if (s == "cd_split") h->cd_split = (int)value;           // 2 = steady-state column steps run split (long genes first, on their own stream); 0 (default) = never (measured: no gain, see use_split)
     else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave; K <= 32, and 32 < K <= 48 with the third slot's columns in LDS), 1 = group kernel, 2 = row16 (LDS, K <= 48)
@@ -2633,12 +2656,18 @@ int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out)
     else if (s == "cd_ms_steady") *out = h->steady_cd_ms;           // option "profile": mean over outer iterations >= 5 of the last call
     else if (s == "col_stats_ms_steady") *out = h->steady_col_ms;
     else if (s == "col_mfma_per_gene") {
-        // v_mfma_f64_16x16x4_f64 instructions the column-side statistics kernel issues per gene (2048 flops each)
+        // v_mfma_f64_16x16x4_f64 instructions the column-side statistics kernel issues per gene (2048 flops each; the 4x4x4 form
+        // of the per-entry kernel is counted in the same unit: a quarter per instruction)
         if (!NB) return fail(INSIDER_ERR_ARG, "no workspace yet: run an update first");
         const int path = col_stats_path(h);
         double v = 0.0;
-        if (path == 0) v = (double)h->col_entries / (double)std::max<int64_t>(h->p, 1) / 4.0 * (NB * (NB + 1) / 2);
-        else
+        if (path == 0) {
+            const int NT = (h->K + 4) / 4;
+            if (h->list_fine && NB == 2 && NT >= 5 && NT <= 8 && h->fperm)   // k_list_stats4: NT (NT + 1) / 2 instructions of 512 flops per 16 entries
+                v = (double)h->col_entries / (double)std::max<int64_t>(h->p, 1) / 16.0 * (NT * (NT + 1) / 2) / 4.0;
+            else
+                v = (double)h->col_entries / (double)std::max<int64_t>(h->p, 1) / 4.0 * (NB * (NB + 1) / 2);
+        } else
             for (int t = 0; t < h->cf.c; ++t) {
                 v += std::ceil(h->cf.L[t] / 4.0) * NB * NB;                                           // M += A' P
                 if (path == 2 && h->cf.nlater[t] > 0) v += std::ceil(h->cf.L[t] / 16.0) * h->cf.nsteps * NB;   // P = N_j Tab

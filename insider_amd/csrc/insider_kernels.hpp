@@ -609,6 +609,188 @@ k_list_stats(const uint32_t *__restrict__ ptr, const int *__restrict__ lidx, con
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same statistics on v_mfma_f64_4x4x4 (four independent 4x4x4 products per instruction), 16 <= K <= 31
+// ---------------------------------------------------------------------------------------------
+// The 16x16x4 form computes full 16 x 16 blocks: for K + 1 = 26 coordinates 3 blocks = 768 outputs per four entries where
+// the lower triangle of a 4 x 4 tiling has 28 tiles = 448.  Both forms run at the matrix unit's 32 flop per cycle and SIMD
+// (measured, tools/ubench_mfma4.hip: 16 cycles per 4x4x4 instruction, 64 per 16x16x4), so the finer tiling is worth
+// NT (NT + 1) / 2 x 16 cycles per 16 entries against NBLK x 4 x 64: 448 against 768 at K = 25, 576 against 768 at K = 30.
+// Operand map of the instruction (measured): A[b][i][k] sits in lane 16 k + 4 b + i, B[b][k][j] in lane 16 k + 4 b + j,
+// D[b][i][j] in lane 16 i + 4 b + j.  The four blocks b take FOUR DIFFERENT GROUPS of four entries of a 16-entry batch and
+// all compute the same tile (ti, tj): lane (k, b, i) holds entry e = 4 b + k and fetches its coordinates 4 t + i, t < NT
+// (NT loads of 8 bytes per lane and batch, as many bytes as the 16x16x4 form reads), so the A operand of tile (ti, tj) is
+// the register a[ti] and the B operand a[tj] — no data movement between the loads and the matrix unit.  x rides in
+// coordinate K (the rows of F are zero from K on).  At the end the four blocks' partial sums are added (two DPP rotations
+// per tile) and the record is assembled in LDS in the layout k_list_stats writes (lower 16 x 16 blocks, x row = KP - 1).
+// What bounds it: every load instruction touches 16 rows where k_list_stats' touch 4 whole 128-byte lines.  With 8-byte loads (32
+// bytes of each row per instruction, 3.5 x the cache-line look-ups) the kernel is bound by the texture addresser as much as by the
+// matrix unit: c5's statistics 0.69 -> 0.61 ms per launch, not the 0.42 the instruction count promises.  So the rows are read
+// from a COPY of F whose coordinates are interleaved in pairs of tiles (k_tile_perm: position 8 s + 2 i + h holds coordinate
+// 8 s + 4 h + i; 10 us per launch at c5): a lane's coordinates 4 t + i of the tiles t = 2 s, 2 s + 1 are then 16 adjacent bytes, one
+// load instruction fetches two tiles (64 bytes of each row) and the look-ups halve.  (Fetching the rows as k_list_stats does and
+// transposing them through an LDS tile per batch — 8 + 8 + NT more instructions and a wave sync per batch — measured 0.74.)
+constexpr int tiles4(int NT) { return NT * (NT + 1) / 2; }
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Fp[r][8 s + 2 i + h] = F[r][8 s + 4 h + i]   (s < KP / 8, i < 4, h < 2)
+__global__ void __launch_bounds__(256) k_tile_perm(const double *__restrict__ F, int64_t rows, int KP, double *__restrict__ Fp)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= rows * KP) return;
+    const int c = (int)(o % KP), s8 = c >> 3, i = (c >> 1) & 3, hh = c & 1;
+    Fp[o] = F[o - c + 8 * s8 + 4 * hh + i];
+}
+
+template <int NB, int NT>
+__device__ __forceinline__ void syrk4_load(const int *li, const double *lx, int batch, __amdgpu_buffer_rsrc_t rsrc,
+                                           double (&a)[NT], int lane, int K)
+{
+    constexpr int RB = Geo<NB>::KP * 8;
+    const int k = lane >> 4, b = (lane >> 2) & 3, i = lane & 3;
+    const int e = SYRK_BATCH * batch + 4 * b + k;
+    const int idx = li[e];
+    const double xv = lx[e];
+    const int off = idx * RB + i * 16;          // (rows in k_tile_perm's order: tiles 2 s and 2 s + 1 of coordinate lane i are adjacent)
+#pragma unroll
+    for (int s2 = 0; s2 < (NT + 1) / 2; ++s2) {
+        const v4i w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 64 * s2, 0);
+        a[2 * s2] = __hiloint2double(w.y, w.x);
+        if (2 * s2 + 1 < NT) a[2 * s2 + 1] = __hiloint2double(w.w, w.z);
+    }
+    const int tx = K >> 2;                      // wave-uniform
+    const bool mine = i == (K & 3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[t] = (t == tx && mine) ? xv : a[t];
+}
+
+template <int NT>
+__device__ __forceinline__ void syrk4_mfma(const double (&a)[NT], double (&acc)[tiles4(NT)])
+{
+    int q = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj, ++q) acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[ti], a[tj], acc[q], 0, 0, 0);
+}
+
+template <int NB, int NT>
+__device__ __forceinline__ void drain_syrk4(const int *li, const double *lx, int nbatch, __amdgpu_buffer_rsrc_t rsrc,
+                                            double (&acc)[tiles4(NT)], int lane, int K)
+{
+    nbatch = __builtin_amdgcn_readfirstlane(nbatch);
+    double a0[NT], a1[NT];
+    syrk4_load<NB, NT>(li, lx, 0, rsrc, a0, lane, K);
+    for (int b = 0; b < nbatch; b += 2) {
+        syrk4_load<NB, NT>(li, lx, b + 1, rsrc, a1, lane, K);
+        syrk4_mfma<NT>(a0, acc);
+        syrk4_load<NB, NT>(li, lx, b + 2 < nbatch ? b + 2 : nbatch - 1, rsrc, a0, lane, K);   // clamped look-ahead, as in drain_syrk
+        syrk4_mfma<NT>(a1, acc);
+    }
+}
+
+// Same contract as k_list_stats (same lists, same record) except that F arrives in k_tile_perm's coordinate order;
+// 4 (NT - 1) <= K < 4 NT so that the x coordinate K is the last tile's
+template <int NB, int NT, int WPB>
+__global__ void __launch_bounds__(WPB * 64)
+k_list_stats4(const uint32_t *__restrict__ ptr, const int *__restrict__ lidx, const double *__restrict__ lval, int units,
+              int nseg, const double *__restrict__ F, int64_t f_rows, double *__restrict__ stat,
+              const double *__restrict__ base /*KP x KP or null*/, int K)
+{
+    constexpr int KP = Geo<NB>::KP, STAT = Geo<NB>::STAT;
+    static_assert(NT <= 4 * NB, "tiles beyond the padded row");
+    __shared__ int s_li[WPB][2][LIST_BLOCK];
+    __shared__ double s_lx[WPB][2][LIST_BLOCK];
+    __shared__ double s_rec[WPB][STAT];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * WPB + w;
+    if (item >= (int64_t)units * nseg) return;
+    const int u = (int)(item % units), sg = (int)(item / units);
+    double acc[tiles4(NT)];
+#pragma unroll
+    for (int q = 0; q < tiles4(NT); ++q) acc[q] = 0.0;
+    const uint32_t e_begin = ptr[u], e_end = ptr[u + 1];
+    const int total = __builtin_amdgcn_readfirstlane((int)((e_end - e_begin) / LIST_ALIGN));   // batch PAIRS in the line
+    const int per = (total + nseg - 1) / nseg;
+    const int b0 = sg * per, b1 = b0 + per < total ? b0 + per : total;
+    if (b0 < b1) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(F), 0, (int)(f_rows * KP * 8), 0x00020000);
+        const uint32_t first = e_begin + (uint32_t)b0 * LIST_ALIGN, last = e_begin + (uint32_t)b1 * LIST_ALIGN;
+        const int nblk = __builtin_amdgcn_readfirstlane((int)((last - first + LIST_BLOCK - 1) / LIST_BLOCK));
+        const int nbt = __builtin_amdgcn_readfirstlane((int)((last - first) / SYRK_BATCH));   // even
+        constexpr int EPL = LIST_BLOCK / WAVE;
+        int ia[EPL], ib[EPL];
+        double xa[EPL], xb[EPL];
+        auto ld = [&](int blk, int (&ii)[EPL], double (&xx)[EPL]) {
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                const uint32_t e = first + (uint32_t)blk * LIST_BLOCK + (uint32_t)(t * WAVE + lane);
+                const uint32_t ec = e < last ? e : last - 1;   // clamped address, value masked: loads stay unconditional
+                const int iv = lidx[ec];
+                const double xv = lval[ec];
+                ii[t] = e < last ? iv : LIST_PAD;
+                xx[t] = e < last ? xv : 0.0;
+            }
+        };
+        ld(0, ia, xa);
+        ld(1, ib, xb);
+        for (int blk = 0; blk < nblk; ++blk) {
+            int *li = s_li[w][blk & 1];
+            double *lx = s_lx[w][blk & 1];
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) { li[t * WAVE + lane] = ia[t]; lx[t * WAVE + lane] = xa[t]; }
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) { ia[t] = ib[t]; xa[t] = xb[t]; }
+            ld(blk + 2, ib, xb);
+            wave_sync();
+            const int left = nbt - blk * (LIST_BLOCK / SYRK_BATCH);
+            drain_syrk4<NB, NT>(li, lx, left < LIST_BLOCK / SYRK_BATCH ? left : LIST_BLOCK / SYRK_BATCH, rsrc, acc, lane, K);
+        }
+    }
+    // ---- the record: zero it, add up the four blocks of every tile, scatter the tiles (both triangles of a diagonal 16 x 16
+    //      block, as k_list_stats stores them), then write it out with the base applied -----------------------------------
+    double *rec = s_rec[w];
+    for (int o = lane; o < STAT; o += WAVE) rec[o] = 0.0;
+    wave_sync();
+    {
+        const int i = lane >> 4, j = lane & 3;
+        const bool writer = (lane & 12) == 0;      // block b = 0 of each row: lanes 16 i + j
+        int q = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj, ++q) {
+                double v = acc[q];
+                v += dpp_mov_d<0x124>(v);           // row_ror:4
+                v += dpp_mov_d<0x128>(v);           // row_ror:8: every lane of the row now holds the sum over b for its j
+                int ra = 4 * ti + i, cb = 4 * tj + j;
+                // coordinate K is x: its row / column live at KP - 1 in the record; coordinates beyond K are zero padding
+                const bool keep = writer && ra <= K && cb <= K && cb <= ra;
+                ra = ra == K ? KP - 1 : ra;
+                cb = cb == K ? KP - 1 : cb;
+                if (keep) {
+                    const int bi = ra >> 4, bj = cb >> 4;
+                    rec[(bi * (bi + 1) / 2 + bj) * 256 + (ra & 15) * 16 + (cb & 15)] = v;
+                    if (bi == bj) rec[(bi * (bi + 1) / 2 + bj) * 256 + (cb & 15) * 16 + (ra & 15)] = v;
+                }
+            }
+    }
+    wave_sync();
+    double *out = stat + (size_t)item * STAT;
+    for (int o = lane; o < STAT; o += WAVE) {
+        // block blk = (bi, bj) in the order bi-major; element (r16, c16)
+        const int blk = o >> 8, r16 = (o >> 4) & 15, c16 = o & 15;
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+        const int bj = blk - bi * (bi + 1) / 2;
+        const int ra = 16 * bi + r16, cb = 16 * bj + c16;
+        double v = rec[o];
+        if (base && ra < K && cb < K) v = base[ra * KP + cb] - v;
+        out[o] = v;
+    }
+}
+
 // ---- building the lists (once per data set) -----------------------------------------------------------------
 // number of held-out entries of every line (one wave per line)
 __global__ void __launch_bounds__(256) k_count_heldout(const uint8_t *__restrict__ codes, int64_t pitch, int len,

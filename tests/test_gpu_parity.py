@@ -62,6 +62,36 @@ def test_masked_gram_cols_and_rows(oracle, K):
         assert relerr(H[r], XtX) < 1e-11 and relerr(b[r], Xty) < 1e-11, r
 
 
+@pytest.mark.parametrize("K", [16, 19, 20, 23, 24, 25, 27, 28, 30, 31])
+def test_masked_gram_on_the_4x4x4_matrix_instruction(oracle, K):
+    """16 <= K <= 31: the per-entry statistics kernel tiles the augmented outer products 4 x 4 (k_list_stats4: v_mfma_f64_4x4x4,
+    NT = 5 .. 8 tile rows, x in coordinate K, rows read from a tile-pair-interleaved copy of the factor) instead of in 16 x 16
+    blocks (option list_fine = 0).  Every NT and the K at its edges, both sides, ragged and empty lines, against the oracle and
+    against the 16x16x4 form."""
+    w = workloads.small(n=170, p=90, level_counts=(6, 5), K=K, f=0.3, seed=40 + K, with_na=True)
+    w.M_train[7, :] = 1          # sample with nothing held out
+    w.M_train[:, 3] = 0          # gene with everything held out (172 entries: several list blocks)
+    A, C = _rand_factors(w, K + 2)
+    R = _R(w, A)
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    out = {}
+    for fine in (1, 0):
+        ds.set_option("list_fine", fine)
+        out[fine] = (ds.masked_gram_cols(R), ds.masked_gram_rows(C))
+    ds.close()
+    (G, q), (H, b) = out[1]
+    for j in range(w.p):
+        XtX, Xty = oracle.masked_gram_col(w.X[:, j], w.M_train[:, j], R)
+        np.testing.assert_allclose(G[j], XtX, rtol=0, atol=1e-10 * max(np.abs(XtX).max(), 1.0))
+        np.testing.assert_allclose(q[j], Xty, rtol=0, atol=1e-10 * max(np.abs(Xty).max(), 1.0))
+    for r in range(w.n):
+        XtX, Xty = oracle.masked_gram_row(w.X, w.M_train, r, C)
+        np.testing.assert_allclose(H[r], XtX, rtol=0, atol=1e-10 * max(np.abs(XtX).max(), 1.0))
+        np.testing.assert_allclose(b[r], Xty, rtol=0, atol=1e-10 * max(np.abs(Xty).max(), 1.0))
+    (G0, q0), (H0, b0) = out[0]
+    assert relerr(G, G0) < 1e-13 and relerr(q, q0) < 1e-13 and relerr(H, H0) < 1e-13 and relerr(b, b0) < 1e-13
+
+
 def test_masked_gram_edge_masks(oracle):
     # empty held-out set, everything held out, ragged sizes (n, p not multiples of the 128-element chunk)
     w = workloads.small(n=131, p=37, level_counts=(4, 3), K=5, f=0.2, seed=3)
