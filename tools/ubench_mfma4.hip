@@ -45,16 +45,18 @@ __global__ void k_layout(double *out)
 int main()
 {
     double *out;
-    hipMalloc(&out, 256 * 256 * sizeof(double) + 64 * 64 * sizeof(double));
+    hipMalloc(&out, 4 * 256 * 256 * sizeof(double) + 64 * 64 * sizeof(double));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int n = 20000;
+    for (int WPS = 1; WPS <= 4; ++WPS) {   // waves per SIMD (blocks of four waves per CU)
     for (int rep = 0; rep < 2; ++rep) {
         float ms;
-        hipEventRecord(e0); k_small<<<256, 256>>>(out, n); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-        printf("4x4x4 (4 blocks): %.3f ms for %d x 8 per wave, one wave per SIMD: %.2f ns per instruction = %.1f flop/ns/SIMD\n", ms, n, ms * 1e6 / (n * 8.0), 512.0 / (ms * 1e6 / (n * 8.0)));
-        hipEventRecord(e0); k_big<<<256, 256>>>(out, n); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-        printf("16x16x4         : %.3f ms for %d x 4 per wave, one wave per SIMD: %.2f ns per instruction = %.1f flop/ns/SIMD\n", ms, n, ms * 1e6 / (n * 4.0), 2048.0 / (ms * 1e6 / (n * 4.0)));
+        hipEventRecord(e0); k_small<<<dim3(256 * WPS), 256>>>(out, n); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("4x4x4 (4 blocks), %d wave(s) per SIMD: %.3f ms: %.2f ns per instruction and SIMD = %.1f flop/ns/SIMD\n", WPS, ms, ms * 1e6 / (n * 8.0 * WPS), 512.0 / (ms * 1e6 / (n * 8.0 * WPS)));
+        hipEventRecord(e0); k_big<<<dim3(256 * WPS), 256>>>(out, n); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("16x16x4         , %d wave(s) per SIMD: %.3f ms: %.2f ns per instruction and SIMD = %.1f flop/ns/SIMD\n", WPS, ms, ms * 1e6 / (n * 4.0 * WPS), 2048.0 / (ms * 1e6 / (n * 4.0 * WPS)));
+    }
     }
     static double h[64 * 64];
     k_layout<<<1, 64>>>(out);
