@@ -518,8 +518,10 @@ def main():
                 "algorithmic_equiv_GBs": b_gram / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else None,
                 "algorithmic_equiv_tflops": fl_alg / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else None,
                 "row_update": "merged (per (level, gene) pair)" if prof.get("row_merged") else "per-sample statistics (k_list_stats)",
-                "note": ("achieved = executed v_mfma_f64_16x16x4 flops (2048 each) / time against the 78.6 TF f64 matrix peak; the "
-                         "per-entry list form of the same statistics (option col_factored = 0) is the streaming-equivalent kernel")},
+                "note": ("achieved = executed f64 matrix flops (2048 per v_mfma_f64_16x16x4, 512 per v_mfma_f64_4x4x4) / time against the "
+                         "78.6 TF f64 matrix peak; issued back to back from four waves per SIMD the 16x16x4 form sustains 0.60 of that peak on "
+                         "this part (matrix unit busy 0.60 at 2.39 GHz), the 4x4x4 form 0.93 - 0.95 (tools/ubench_mfma4.hip); the per-entry "
+                         "list form of the same statistics (option col_factored = 0) is the streaming-equivalent kernel")},
             "cd_kernel": {"kernel": ("k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)"
                                      if K <= 32 else ("k_cd_cols_reg<3, .> (32 < K <= 48: the same kernel with three coordinate slots per lane, the third slot's Gram columns in LDS: 7 VALU + 1 LDS read per step, two waves per SIMD)"
                                                       if K <= 48 else "k_cd_cols<64, 1> (K > 48: one gene per wavefront, Gram matrix in LDS, v_readlane broadcasts)")),
