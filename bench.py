@@ -362,8 +362,9 @@ def main():
 
     def run(iters, seed, start, lam_):
         A, C = start
+        # copy=False: the factors are updated in place, as the C ABI does it (no second host copy of the result)
         return ds.optimize(A, C, K, lam_, lam_, alpha, tuning=tuning, max_iter=iters - 1, global_tol=-1.0, seed=seed,
-                           inc_continuous=1 if args.ctns > 0 else 0)
+                           inc_continuous=1 if args.ctns > 0 else 0, copy=False)
 
     def sync():
         if world > 1:
@@ -481,7 +482,7 @@ def main():
                        "value_is": (f"{slabs} x outer iterations/s of the {n}x{p_total} problem (one {name}-sized gene slab per GPU)"
                                     if slabs > 1 else f"outer iterations/s of the {n}x{p_total} problem"),
                        "sub_tol": 1e-5, "global_tol": "off (fixed iteration count)",
-                       "timed_call": f"one optimize() of {args.steps} outer iterations from fresh N(0, 1e-6) inits (cold start included)",
+                       "timed_call": f"one optimize() of {args.steps} outer iterations from fresh N(0, 1e-6) inits (cold start and the factor transfers included; factors updated in place, as the C ABI does)",
                        "warmup_call": "a neighbouring grid point (other lambda, inits, sweep seed)" if args.warmup > 0 else "none",
                        "parallelism": (f"gene-shard x{world}, exchange: {exchange if isinstance(exchange, str) else type(exchange).__name__}"
                                        + (" (REHEARSAL: all ranks on one GPU, host-staged all-reduce)" if one_gpu else ""))

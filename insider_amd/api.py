@@ -129,7 +129,10 @@ class InsiderData:
         return Cw.copy()
 
     def optimize(self, cfd_factors, column_factor, latent_dim, lambda1=1.0, lambda2=1.0, alpha=0.1, tuning=1,
-                 global_tol=1e-10, sub_tol=1e-5, max_iter=10000, seed=DEFAULT_SEED, inc_continuous=0, traj_cap=4096):
+                 global_tol=1e-10, sub_tol=1e-5, max_iter=10000, seed=DEFAULT_SEED, inc_continuous=0, traj_cap=4096,
+                 copy=True):
+        """copy=False: the returned factors ARE the (updated in place) arguments instead of copies of them — what the C ABI
+        itself does; the reference's List holds copies (src/optimize.cpp:413), hence the default."""
         lib = _lib.load()
         K = int(latent_dim)
         A, Cw, Aptrs = self._marshal(cfd_factors, column_factor, K, inc_continuous)
@@ -146,7 +149,8 @@ class InsiderData:
                 dst[...] = src
         if Cw is not column_factor and isinstance(column_factor, np.ndarray):
             column_factor[...] = Cw
-        return dict(row_matrices={f"factor{i}": a.copy() for i, a in enumerate(A)}, column_factor=Cw.copy(),
+        return dict(row_matrices={f"factor{i}": (a.copy() if copy else a) for i, a in enumerate(A)},
+                    column_factor=Cw.copy() if copy else Cw,
                     train_rmse=tr.value, test_rmse=te.value, loss=lo.value, traj=traj[: rows.value].copy(),
                     iters=iters.value)
 

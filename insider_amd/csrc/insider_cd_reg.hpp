@@ -474,7 +474,7 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[reg_r
             s_w[64 * u] = w1;
         }
         const double dloss = row16_sum(la * (acc1 + acc));
-        if (sweep > win) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);                   // wave-uniform, limited passes only
+        if (__builtin_expect(sweep > win, 0)) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);   // wave-uniform, limited passes only
         const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
         if (cand != 0) {                                                                    // wave-uniform, rarely taken
             // lane masks are formed here, from a laundered lane id, and not kept in registers across the sweeps
