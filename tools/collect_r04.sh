@@ -12,6 +12,7 @@ cp $(ls -t $S/prof_c5/*/*kernel_stats.csv | head -1) $D/c5_kernel_stats.csv
 cp $S/c3_steady_iteration_timeline.txt $S/c3_trace_avg.txt $S/slab8.log $S/slab8_timeline.txt $S/concurrent_grids.log $D/ 2>/dev/null
 cp $S/c3_pmc_issue.csv $D/c3_pmc_issue.csv
 cp $S/c3_K40_pmc_issue.csv $D/c3_K40_pmc_issue.csv 2>/dev/null
+cp $S/c5_pmc_issue.csv $D/c5_pmc_issue.csv 2>/dev/null
 cp $S/issue.json $R/profiles/issue.json
 python3 $R/tools/pmc_csv.py $S/pmc_fetch $S/pmc_write > $D/c3_pmc_summary.csv
 cd $R && python3 tools/pmc_traffic.py c3 $S/pmc_fetch $S/pmc_write $(git rev-parse --short HEAD)

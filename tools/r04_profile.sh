@@ -11,7 +11,7 @@ export GPU_MAX_HW_QUEUES=32
 cd /tmp && export TMPDIR=/tmp
 python3 -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; g.build()" || exit 1
 B="python3 $R/bench.py"
-rm -rf $OUT/prof_c3 $OUT/prof_c5 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_issue_c3_1 $OUT/pmc_issue_c3_2 $OUT/pmc_issue_c3_3 $OUT/pmc_issue_c3_K40_1 $OUT/pmc_issue_c3_K40_2 $OUT/pmc_issue_c3_K40_3
+rm -rf $OUT/prof_c3 $OUT/prof_c5 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_issue_c3_1 $OUT/pmc_issue_c3_2 $OUT/pmc_issue_c3_3 $OUT/pmc_issue_c3_K40_1 $OUT/pmc_issue_c3_K40_2 $OUT/pmc_issue_c3_K40_3 $OUT/pmc_issue_c5_1 $OUT/pmc_issue_c5_2 $OUT/pmc_issue_c5_3
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c3 -- $B --no-cpu-baseline > $OUT/prof_c3.json 2> $OUT/prof_c3.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5 -- $B --workload c5 --no-cpu-baseline > $OUT/prof_c5.json 2> $OUT/prof_c5.err || exit 1
 echo "kernel traces done"
@@ -20,6 +20,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --steps 4
 echo "traffic passes done"
 bash $R/tools/pmc_issue.sh $TAG c3 > $OUT/pmc_issue.log 2>&1 || { tail -5 $OUT/pmc_issue.log; exit 1; }
 bash $R/tools/pmc_issue.sh $TAG c3 "--latent 40" c3_K40 > $OUT/pmc_issue_K40.log 2>&1 || { tail -5 $OUT/pmc_issue_K40.log; exit 1; }
+bash $R/tools/pmc_issue.sh $TAG c5 > $OUT/pmc_issue_c5.log 2>&1 || { tail -5 $OUT/pmc_issue_c5.log; exit 1; }
 echo "issue passes done"
 cd $R
 python3 tools/iter_timeline.py $OUT/prof_c3 6 > $OUT/c3_steady_iteration_timeline.txt 2>&1
