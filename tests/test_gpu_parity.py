@@ -505,6 +505,16 @@ def test_inplace_update_and_oneshot_operator(oracle):
     ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha,
                           max_iter=3, seed=5)
     assert relerr(C, ref["column_factor"]) < 1e-8
+    # the List the reference returns holds COPIES (src/optimize.cpp:413): the default; copy=False hands back the arguments
+    # themselves (what the C ABI does, and what bench.py times), with the same numbers
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    A1, C1 = [a.copy(order="F") for a in w.A0], w.C0.copy(order="F")
+    A2, C2 = [a.copy(order="F") for a in w.A0], w.C0.copy(order="F")
+    r1 = ds.optimize(A1, C1, w.K, w.lam, w.lam, w.alpha, max_iter=3, seed=5)
+    r2 = ds.optimize(A2, C2, w.K, w.lam, w.lam, w.alpha, max_iter=3, seed=5, copy=False)
+    ds.close()
+    assert r1["column_factor"] is not C1 and r2["column_factor"] is C2 and r2["row_matrices"]["factor0"] is A2[0]
+    assert np.array_equal(C1, C2) and np.array_equal(r1["column_factor"], C2) and np.array_equal(A1[0], A2[0])
 
 
 def test_global_tol_early_stop(oracle):
