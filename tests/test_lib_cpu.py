@@ -173,11 +173,20 @@ def test_sweep_kernels_do_not_spill(tmp_path, lib):
         for i in range(sites[0] + 1, len(ins)):
             addr, t, rest = ins[i]
             m = _re.search(r"<([^>+]+)(?:\+0x([0-9a-f]+))?>", rest) if _re.match(r"s_c?branch", t) else None
+            target = None
             if m and m.group(1) in labels:
                 target = labels[m.group(1)] + int(m.group(2) or "0", 16)
-                if target <= a0 and a0 - target < 256:
-                    back = (i, target)
-                    break
+            elif t.startswith("s_setpc_b64 s[") and i >= 3 and ins[i - 3][1].startswith("s_getpc_b64"):
+                # a relaxed (long) branch: s_getpc_b64 / s_add_u32 lo, lo, imm32 / s_addc_u32 hi, hi, -1|0 / s_setpc_b64 — the KMAX = 30
+                # kernel's table of two-step blocks (62 KB, aligned to 64 KiB) lies inside its sweep loop
+                ma = _re.match(r"s_add_u32 s\d+, s\d+, (0x[0-9a-f]+|-?\d+)", ins[i - 2][1])
+                if ma:
+                    imm = int(ma.group(1), 0)
+                    imm -= (1 << 32) if imm >= (1 << 31) else 0
+                    target = ins[i - 2][0] + imm
+            if target is not None and target <= a0 and a0 - target < 256:
+                back = (i, target)
+                break
         assert back is not None, head
         body = [t for addr, t, _r in ins[: back[0] + 1] if addr >= back[1]]
         assert len(body) > 100, (head, len(body))                     # the whole sweep (code blocks + loss bookkeeping) is in it
