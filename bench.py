@@ -542,10 +542,12 @@ def main():
                           "valu_issue_model_clock_GHz": cd_clock / 1e9,
                           "valu_busy_measured": cd_issue.get("valu_busy_of_resident_simd_time"),
                           "issue_counters": cd_issue or None, "issue_counters_note": inote,
-                          "bound_note": ("one computed jump per coordinate step: a CU sustains about one taken branch per 4.7 ns at every "
-                                         "occupancy (tools/ubench5.hip, ubench6.hip), so four SIMDs step at most once per ~19 ns each against "
-                                         "13 ns of vector issue; A/B on one box (profiles/r04/exp_quick): a sweep with 25 fewer vector "
-                                         "instructions is slower, a sweep with one taken branch fewer (33 -> 32) is 0.8 % faster (DESIGN.md 4.2)"),
+                          "bound_note": ("one computed jump per coordinate step, three waves per SIMD (161 VGPRs at K = 30): a chain of jump-dispatched "
+                                         "blocks of the step's shape paces per WAVE (tools/ubench8.hip: 27 ns per block for a lone wave, 54 - 55 ns per "
+                                         "wave at 3 and at 4 waves per SIMD = 18.1 / 13.7 ns per SIMD, table sizes 2 ... 64 KB alike) against 13 ns of "
+                                         "vector issue per step; A/B on one box (profiles/r04/exp_quick): a sweep with 25 fewer vector instructions is "
+                                         "slower, one taken branch fewer per sweep (33 -> 32) is 0.8 % faster, a third fewer jumps (blocks of two steps) "
+                                         "gain nothing at full occupancy (DESIGN.md 4.2, 9)"),
                           "share_of_wall": prof["cd_ms"] / (dt * 1e3),
                           # the reference's sweep loop has no cap (src/coordinate_descent.cpp:86-114): solves this call ended
                           # at the library's max_sweeps without convergence (must be 0), and the longest solve
