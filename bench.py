@@ -331,20 +331,14 @@ def main():
         Z = np.asfortranarray(np.random.Generator(np.random.PCG64([workloads.DATA_SEED, 7])).standard_normal((n, args.ctns)))
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, device=local_rank, ctns_confounder=Z)
     t_up = time.perf_counter() - t0
-    if world > 1 and not one_gpu:
-        # in-library RCCL (ncclAllReduce on the library's stream); if any rank cannot join, all ranks fall back together
-        # to the torch.distributed callback
-        joined, exchange = 1, None
-        try:
-            exchange = idist.attach(ds, lo, rank, world, device=local_rank, mode="rccl")
-        except Exception as e:
-            joined = 0
-            print(f"[bench rank {rank}] in-library RCCL unavailable ({e!r}); falling back to the torch.distributed callback",
-                  file=sys.stderr, flush=True)
-        flag = torch.tensor([joined], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            exchange = idist.attach(ds, lo, rank, world, device=local_rank, mode="torch")
+    exchange_vote = None
+    if world > 1 and (not one_gpu or os.environ.get("INSIDER_BENCH_REHEARSE_VOTE") == "1"):
+        # in-library RCCL (ncclAllReduce on the library's stream) when EVERY rank can join it; else all ranks fall back
+        # together — two votes around the blocking join, insider_amd/dist.py:attach_voted.  (One-GPU rehearsal: the vote
+        # itself is rehearsed with INSIDER_BENCH_REHEARSE_VOTE=1 + INSIDER_FAIL_COMM_RANK; the fall-back there is the
+        # host-staged exchange, RCCL refusing two ranks on one device.)
+        exchange, exchange_vote = idist.attach_voted(ds, lo, rank, world, device=local_rank, fallback="staged" if one_gpu else "torch",
+                                                     log=lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
     else:
         exchange = idist.attach(ds, lo, rank, world, device=local_rank, staged=one_gpu)
     ds.set_option("profile", 1)
@@ -486,7 +480,8 @@ def main():
                        "warmup_call": "a neighbouring grid point (other lambda, inits, sweep seed)" if args.warmup > 0 else "none",
                        "parallelism": (f"gene-shard x{world}, exchange: {exchange if isinstance(exchange, str) else type(exchange).__name__}"
                                        + (" (REHEARSAL: all ranks on one GPU, host-staged all-reduce)" if one_gpu else ""))
-                                      if world > 1 else "single GPU"},
+                                      if world > 1 else "single GPU",
+                       "exchange_vote": exchange_vote},
             "roofline": {
                 "kernel": ("column step = masked Gram/XtY statistics [" + kern + "] + elastic-net sweeps [k_cd_cols_reg]: the "
                            "dominant kernel pair (SURVEY.md 8d prices them as one 'column-side masked-Gram/XtY (+fused CD)' pass)"),

@@ -233,6 +233,24 @@ int insider_hip_strong_cd_xy(const double *X, const double *y, int64_t m, int K,
  * device code. */
 int insider_hip_solve_sympd(const double *A, const double *b, int K, int64_t nsys, int device, double *x, int32_t *route);
 
+/* optimize_continuous_v2 with the reference's eight arguments (src/optimize.cpp:76-137; .Call symbol
+ * `_insider_optimize_continuous_v2`, src/RcppExports.cpp:69-85, R/RcppExports.R:16-18): the update of ONE continuous
+ * covariate's K-vector against an arbitrary n x p matrix `data` (inside optimize() it is the Gauss-Seidel residual with this
+ * column's own contribution added back, src/optimize.cpp:344-345).
+ *   data             n x p column-major
+ *   indicator        n x p uint8, non-zero = the entry takes part (train_indicator); read only when tuning = 1
+ *   updating_factor  K doubles, IN/OUT (the reference's rowvec&)
+ *   c_factor         K x p column-major (column_factor)
+ *   updating_confd   n doubles (one column of ctns_confounder)
+ *   gram             K x K column-major (column_factor column_factor'); read only when tuning = 0, exactly like the reference
+ * tuning = 1: cyclic scalar passes u_i = Xty_i / (XtX_i + lambda) over the masked entries until sum |du| < 0.1 (:102-126);
+ * tuning = 0: one solve of ((z'z) gram + lambda I) u = C data' z (:127-131, solve(..., likely_sympd)).  Any other value:
+ * INSIDER_ERR_ARG (the reference prints and exit(1)s, :133-136).  Inside a fit the same update runs on the resident data set
+ * (insider_hip_optimize / insider_hip_optimize_row with cov >= c); this entry uploads its arguments, runs and frees. */
+int insider_hip_optimize_continuous_v2(const double *data, int64_t n, int64_t p, const uint8_t *indicator,
+                                       double *updating_factor, const double *c_factor, int K, const double *updating_confd,
+                                       const double *gram, double lambda, int tuning, int device);
+
 /*
  * The masked Gram / XtY reductions on their own (for parity tests and profiling).
  * Column side (src/optimize.cpp:216-222): for every gene j, XtX_j = R'R - sum_{i: M_train[i,j]=0} r_i r_i',

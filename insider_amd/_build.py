@@ -25,13 +25,18 @@ def source_files():
     return fs
 
 
-def source_sha():
-    """sha256 (first 16 hex digits) over insider_amd/csrc/*.{hip,hpp}, include/*.h and the compiler flags."""
+def source_sha(extra_flags=()):
+    """sha256 (first 16 hex digits) over insider_amd/csrc/*.{hip,hpp}, include/*.h and the compiler flags.  A VARIANT build
+    (extra_flags: -D switches of the A/B tools and of tests/test_gpu_period.py) hashes its extra flags too, so it never
+    carries the hash of the canonical build: written to the default path it is rebuilt before use, and bench.py does not
+    attach the canonical library's counter figures to it."""
     h = hashlib.sha256()
     for f in source_files():
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    if extra_flags:
+        h.update(b"\0variant\0" + " ".join(extra_flags).encode())
     return h.hexdigest()[:16]
 
 
@@ -53,14 +58,14 @@ def needs_build(path=HIP_LIB):
 def build_library(force=False, extra_flags=(), out=HIP_LIB):
     """Compile the library for gfx950 (hipcc cross-compiles without a GPU).  Serialised across processes by a file lock:
     several ranks / test workers may find the same stale binary at once."""
-    lock = open(os.path.join(_HERE, ".build.lock"), "w")
+    lock = open(os.path.join(_HERE, ".build.lock"), "w")      # (git-ignored: a runtime artefact)
     fcntl.flock(lock, fcntl.LOCK_EX)
     try:
         if not force and not extra_flags and library_sha(out) == source_sha():
             return False
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         tmp = out + ".tmp.so"
-        cmd = [hipcc] + FLAGS + list(extra_flags) + [f'-DINSIDER_SOURCE_SHA="{source_sha()}"', "-o", tmp, HIP_SRC,
+        cmd = [hipcc] + FLAGS + list(extra_flags) + [f'-DINSIDER_SOURCE_SHA="{source_sha(extra_flags)}"', "-o", tmp, HIP_SRC,
                                                      "-L/opt/rocm/lib", "-lrccl"]
         subprocess.check_call(cmd, cwd=ROOT)
         os.replace(tmp, out)

@@ -26,6 +26,7 @@ SYMBOLS = (
     "insider_hip_masked_gram_rows", "insider_hip_get_profile", "insider_hip_get_sweeps", "insider_hip_last_cd_ms",
     "insider_hip_optimize_oneshot_ex", "insider_hip_strong_cd_xy", "insider_hip_solve_sympd", "insider_hip_get_info",
     "insider_hip_comm_unique_id", "insider_hip_comm_init", "insider_hip_get_array", "insider_hip_clone",
+    "insider_hip_optimize_continuous_v2",
 )
 COMM_ID_BYTES = 128
 
@@ -89,6 +90,8 @@ def load():
     lib.insider_hip_strong_cd_xy.argtypes = [dp, dp, C.c_int64, C.c_int, dp, C.c_double, C.c_double, dp, dp, C.c_double,
                                              C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, dp, i32p]
     lib.insider_hip_solve_sympd.argtypes = [dp, dp, C.c_int, C.c_int64, C.c_int, dp, i32p]
+    lib.insider_hip_optimize_continuous_v2.argtypes = [dp, C.c_int64, C.c_int64, u8p, dp, dp, C.c_int, dp, dp, C.c_double,
+                                                       C.c_int, C.c_int]
     lib.insider_hip_get_info.argtypes = [C.c_void_p, C.c_char_p, dp]
     lib.insider_hip_get_array.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.insider_hip_comm_unique_id.argtypes = [C.c_void_p, C.c_int]

@@ -5,6 +5,7 @@ Operator level (names and argument meaning of /root/reference/R/RcppExports.R:4-
              test_indicator, inc_continuous, latent_dim, lambda1, lambda2, alpha, tuning, global_tol,
              sub_tol, max_iter)
     strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX, Xty, tol)
+    optimize_continuous_v2(data, indicator, updating_factor, c_factor, updating_confd, gram, lambda_, tuning)
 Caller level (R/insider.R:18-216, R/utils.R:40-43,78-117) — R is absent from this pipeline, so the R S3 API is
 mirrored here in Python with the same names, defaults and error behaviour:
     insider(), tune(), fit(), ratio_splitter(), init_parameters()
@@ -62,11 +63,13 @@ class InsiderData:
         other.n, other.p, other.c, other.m, other.n_levels = self.n, self.p, self.c, self.m, self.n_levels
         other._h = C.c_void_p()
         other._cb = None
+        other._options = dict(getattr(self, "_options", {}))       # the library copies the options as they stand
         _lib.check(_lib.load().insider_hip_clone(self._h, C.byref(other._h)))
         return other
 
     def set_option(self, name, value):
         _lib.check(_lib.load().insider_hip_set_option(self._h, name.encode(), float(value)))
+        self.__dict__.setdefault("_options", {})[name] = float(value)      # (what tune(concurrent=k) re-applies to its clones)
 
     def set_shard(self, gene_offset, rank, world, allreduce=None):
         """allreduce(ptr:int, count:int, stream:int) -> None sums `count` doubles at device pointer `ptr` across ranks in
@@ -321,6 +324,39 @@ def strong_coordinate_descent(X, y, wstart, lambda_, alpha, XtX=None, Xty=None, 
     return (beta, sw) if return_sweeps else beta
 
 
+def optimize_continuous_v2(data, indicator, updating_factor, c_factor, updating_confd, gram, lambda_, tuning, device=0):
+    """optimize_continuous_v2() of R/RcppExports.R:16-18 (src/optimize.cpp:76-137), the reference's eight arguments, through
+    ``insider_hip_optimize_continuous_v2``: the update of one continuous covariate's K-vector against the matrix ``data``
+    (n x p; inside optimize() the residual with this column's contribution added back, :344-345).  ``updating_factor`` is
+    updated IN PLACE when it is a float64 array (the reference's ``rowvec&``) and returned.  ``indicator`` is read only when
+    tuning = 1, ``gram`` only when tuning = 0 — as in the reference."""
+    if tuning not in (0, 1):
+        raise InsiderError(_lib.ERR_ARG, "Parameter tuning should be either 0 or 1!")
+    D = _lib.f64(data)
+    n, p = D.shape
+    Cm = _lib.f64(c_factor)
+    K = Cm.shape[0]
+    z = np.ascontiguousarray(np.asarray(updating_confd, dtype=np.float64).reshape(-1))
+    u = np.ascontiguousarray(np.asarray(updating_factor, dtype=np.float64).reshape(-1)).copy()
+    if Cm.shape != (K, p) or z.shape != (n,) or u.shape != (K,):
+        raise InsiderError(_lib.ERR_ARG, "c_factor must be K x p, updating_confd of length n, updating_factor of length K")
+    M = g = None
+    if tuning == 1:
+        M = np.asfortranarray(np.asarray(indicator) != 0, dtype=np.uint8)
+        if M.shape != (n, p):
+            raise InsiderError(_lib.ERR_ARG, "indicator shape must match data")
+    else:
+        g = _lib.f64(gram)
+        if g.shape != (K, K):
+            raise InsiderError(_lib.ERR_ARG, "gram must be K x K")
+    _lib.check(_lib.load().insider_hip_optimize_continuous_v2(
+        _lib.ptr(D), n, p, _lib.ptr(M, C.c_uint8) if M is not None else None, _lib.ptr(u), _lib.ptr(Cm), K, _lib.ptr(z),
+        _lib.ptr(g) if g is not None else None, float(lambda_), int(tuning), int(device)))
+    if isinstance(updating_factor, np.ndarray) and updating_factor.dtype == np.float64:
+        updating_factor.reshape(-1)[...] = u
+    return u
+
+
 def solve_sympd(A, b, device=0, return_route=False):
     """solve(A, b, solve_opts::likely_sympd) (src/optimize.cpp:175,190,226,240), batched: A (B, K, K) or (K, K), b (B, K)
     or (K,).  Cholesky first, Gaussian elimination with partial pivoting when A is not positive definite."""
@@ -470,9 +506,19 @@ def _nearest_finished(done, g, n_lambda):
 def _tune_handles(obj, ds, k):
     """k handles on the resident tune() data set: the data set's own plus k - 1 clones (insider_hip_clone: shared device
     arrays, private workspaces), kept on the object for the next call."""
-    clones = obj.setdefault("_tune_clones", [])
+    # clones whose handle has been closed since (bench.py closes them between grids) are dropped; the others are dropped too
+    # when they belong to another data set handle than `ds` (a re-created resident data set)
+    clones = [hd for hd in obj.get("_tune_clones", []) if getattr(hd, "_h", None) and getattr(hd, "_src", None) is ds]
     while len(clones) < k - 1:
-        clones.append(ds.clone())
+        hd = ds.clone()
+        hd._src = ds
+        clones.append(hd)
+    obj["_tune_clones"] = clones
+    # a clone copies its source's options as they stood at clone time: bring the ones set on `ds` since then across
+    for hd in clones[: k - 1]:
+        for name, value in getattr(ds, "_options", {}).items():
+            if getattr(hd, "_options", {}).get(name) != value:
+                hd.set_option(name, value)
     return [ds] + clones[: k - 1]
 
 
@@ -560,12 +606,18 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
             errors = []
 
             def _producer():
-                for g in range(len(grid)):
-                    v, t_draw = _draw()
-                    if g % world == rank:
-                        ready.put((g, v, t_draw))
-                for _ in handles:
-                    ready.put(None)
+                try:
+                    for g in range(len(grid)):
+                        if errors:
+                            break
+                        v, t_draw = _draw()
+                        if g % world == rank:
+                            ready.put((g, v, t_draw))
+                except BaseException as e:      # a failed draw (MemoryError, ...) must not leave the workers waiting for ever
+                    errors.append(e)
+                finally:
+                    for _ in handles:           # one sentinel per worker, whatever happened above
+                        ready.put(None)
 
             def _worker(hd):
                 while True:

@@ -503,12 +503,16 @@ int launch_mm_reduce_kp(insider_hip_handle *h, const double *X, int64_t ldx, con
 int r16_wide_lds(size_t bytes)
 {
     if (bytes > 160 * 1024) return fail(INSIDER_ERR_UNSUPPORTED, "K too large for the LDS-resident sweep kernel");
-    static std::atomic<bool> done{false};
-    if (!done.load()) {
+    // the attribute belongs to the CURRENT device's function object: one flag per device (a process may drive several GPUs)
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev >= 64 || !(done.load() & bit)) {
         const int lim = 160 * 1024;
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cd_cols_r16<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cd_batch_r16<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        done.store(true);
+        done.fetch_or(bit);
     }
     return INSIDER_OK;
 }
@@ -1214,6 +1218,9 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
             hipLaunchKernelGGL((k_gene_u_cnt<4>), dim3(cdiv(h->p, 4)), dim3(256), gu_lds, h->stream, ca, h->cf_pos[i], LP,
                                (const double *)h->Vlev, h->SLP, h->SL, h->U);
         } else {
+            // (k_gene_u knows nothing of the continuous covariates' term: insider_hip_create_ex leaves cont_merged off when a
+            // covariate's k_gene_u_cnt record does not fit, so this branch is never reached with m > 0)
+            if (h->m > 0) return fail(INSIDER_ERR_UNSUPPORTED, "merged row update with continuous covariates needs the pair-count form");
             hipLaunchKernelGGL((k_gene_u<4>), dim3(cdiv(h->p, 4)), dim3(256), (size_t)4 * (h->SLcat + GU_TILE) * sizeof(double),
                                h->stream, (const uint32_t *)ct.grp, (const uint16_t *)ct.slev,
                                (size_t)h->col_entries + LIST_BLOCK, h->c - 1, L, LP, (const double *)h->Vlev, h->SLP, (int)h->p,
@@ -1953,7 +1960,14 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
             cf.m = m;
             cf.SLcat = h->SLcat;
             for (int t = 0; t < c; ++t) cf.pos_cov[t] = ord[t];
-            if (m > 0 && h->cf_pair_ok) {
+            // The merged row update with continuous columns takes u_j from k_gene_u_cnt ALONE (only it adds the term of the
+            // real-valued counts, ColFacArgs::zt; k_gene_u reads the categorical columns of V only): every covariate's launch
+            // of it must fit its per-wave LDS record — V row [SL] | out [LP] | GU_BATCH x 64 partial sums, four waves per block
+            // — or the whole data set stays on the per-sample / per-entry paths (a covariate with ~770 levels or more).
+            bool gu_fits = true;
+            for (int t = 0; t < c; ++t)
+                gu_fits = gu_fits && (size_t)4 * (h->SL + round_up(h->n_levels[t], 2) + GU_BATCH * WAVE) * sizeof(double) <= 64 * 1024;
+            if (m > 0 && h->cf_pair_ok && gu_fits) {
                 // continuous covariates on the pair-count form: one more position (the m columns as pseudo-levels, no count
                 // bytes, 1/2 n = 0: sixteen more zero floats per gene would do, the block reads what follows its offset ->
                 // its own zero region) and the real-valued count table
@@ -1993,10 +2007,15 @@ int insider_hip_create_ex(const double *X, int64_t n, int64_t p, const int32_t *
                 const int lip[2] = {0, (int)ib.size()};
                 int *d_idx = nullptr, *d_lip = nullptr;
                 uint32_t *d_ib = nullptr, *d_ie = nullptr;
+                // (owned by contm[0] from the moment they exist: free_data_set releases them on every error path below)
                 CR(dmalloc(&d_idx, plen_l + LIST_BLOCK));
+                h->contm[0].wl_idx = d_idx;
                 CR(dmalloc(&d_ib, ib.size() + 1));
+                h->contm[0].item_begin = d_ib;
                 CR(dmalloc(&d_ie, ie.size() + 1));
+                h->contm[0].item_end = d_ie;
                 CR(dmalloc(&d_lip, 2));
+                h->contm[0].lvl_item_ptr = d_lip;
                 CH(hipMemcpy(d_idx, widx.data(), plen_l * sizeof(int), hipMemcpyHostToDevice));
                 CH(hipMemcpy(d_ib, ib.data(), ib.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
                 CH(hipMemcpy(d_ie, ie.data(), ie.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -2568,6 +2587,79 @@ int insider_hip_solve_sympd(const double *A, const double *b, int K, int64_t nsy
         singular = singular || hr[i] < 0;
     }
     if (singular) return fail(INSIDER_ERR_SOLVE, "a system is singular to working precision");
+    return INSIDER_OK;
+}
+
+// optimize_continuous_v2 (src/optimize.cpp:76-137) with the reference's eight arguments, on an arbitrary `data` matrix
+// (insider_cont_v2.hpp): one streaming pass over (data, indicator) for the per-gene sums, the K x K weighted Gram, then the
+// reference's cyclic scalar passes (tuning = 1, k_cont_cd) or its one ridge solve (tuning = 0, k_level_solve).
+int insider_hip_optimize_continuous_v2(const double *data, int64_t n, int64_t p, const uint8_t *indicator,
+                                       double *updating_factor, const double *c_factor, int K, const double *updating_confd,
+                                       const double *gram, double lambda, int tuning, int device)
+{
+    if (tuning != 0 && tuning != 1)   // the reference prints and exit(1)s (src/optimize.cpp:133-136)
+        return fail(INSIDER_ERR_ARG, "Parameter tuning should be either 0 or 1!");
+    if (!data || !updating_factor || !c_factor || !updating_confd) return fail(INSIDER_ERR_ARG, "null argument");
+    if (tuning == 1 && !indicator) return fail(INSIDER_ERR_ARG, "tuning = 1 needs the indicator matrix");
+    if (tuning == 0 && !gram) return fail(INSIDER_ERR_ARG, "tuning = 0 needs gram (K x K)");
+    if (n < 1 || p < 1) return fail(INSIDER_ERR_ARG, "n and p must be >= 1");
+    if (!(lambda == lambda)) return fail(INSIDER_ERR_ARG, "lambda is NaN");
+    if (K < 1 || K > INSIDER_MAX_K) return fail(INSIDER_ERR_UNSUPPORTED, "K must be in 1..63");
+    int rc = cd_common_checks(K, 1, device);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(device));
+    const int NB = (K + 1 + 15) / 16, KP = 16 * NB, len = KP * KP + KP;
+    const int nslab = cdiv(p, CV2_SLAB);
+    const size_t np = (size_t)n * (size_t)p;
+    DevBufs bufs;
+    double *dD = nullptr, *dC = nullptr, *dz = nullptr, *dw = nullptr, *dt = nullptr, *dpart = nullptr, *deq = nullptr, *du = nullptr,
+           *dg = nullptr, *dzz = nullptr;
+    uint8_t *dM = nullptr;
+    int *dflag = nullptr;   // [0] the solve's fail flag, [1] a level count of 1 for k_level_solve
+    if ((rc = bufs.alloc(&dD, np)) || (rc = bufs.alloc(&dC, (size_t)K * p)) || (rc = bufs.alloc(&dz, (size_t)n)) ||
+        (rc = bufs.alloc(&dt, (size_t)p)) || (rc = bufs.alloc(&dpart, (size_t)nslab * len)) || (rc = bufs.alloc(&deq, (size_t)len)) ||
+        (rc = bufs.alloc(&du, (size_t)KP)) || (rc = bufs.alloc(&dflag, 2)))
+        return rc;
+    HIPCHECK(hipMemcpy(dD, data, np * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dC, c_factor, (size_t)K * p * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dz, updating_confd, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemset(du, 0, (size_t)KP * sizeof(double)));
+    HIPCHECK(hipMemcpy(du, updating_factor, (size_t)K * sizeof(double), hipMemcpyHostToDevice));
+    const int flag0[2] = {0, 1};
+    HIPCHECK(hipMemcpy(dflag, flag0, sizeof(flag0), hipMemcpyHostToDevice));
+    if (tuning == 1) {
+        if ((rc = bufs.alloc(&dM, np)) || (rc = bufs.alloc(&dw, (size_t)p))) return rc;
+        HIPCHECK(hipMemcpy(dM, indicator, np, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL((k_cv2_gene<true>), dim3(cdiv(p, 4)), dim3(256), 0, 0, (const double *)dD, (const uint8_t *)dM,
+                           (const double *)dz, n, p, dw, dt);
+    } else {
+        if ((rc = bufs.alloc(&dg, (size_t)K * K)) || (rc = bufs.alloc(&dzz, 1))) return rc;
+        HIPCHECK(hipMemcpy(dg, gram, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_cv2_zz, dim3(1), dim3(64), 0, 0, (const double *)dz, n, dzz);
+        hipLaunchKernelGGL((k_cv2_gene<false>), dim3(cdiv(p, 4)), dim3(256), 0, 0, (const double *)dD, (const uint8_t *)nullptr,
+                           (const double *)dz, n, p, (double *)nullptr, dt);
+    }
+    KCHECK();
+    hipLaunchKernelGGL(k_cv2_eq_part, dim3(nslab), dim3(256), 0, 0, (const double *)dC, (const double *)dw, (const double *)dt, K, KP,
+                       p, dpart);
+    KCHECK();
+    hipLaunchKernelGGL(k_cv2_eq_sum, dim3(cdiv(len, 256)), dim3(256), 0, 0, (const double *)dpart, nslab, K, KP,
+                       (const double *)dg, (const double *)dzz, deq);
+    KCHECK();
+    NB_DISPATCH(NB, {
+        (void)WPB_;
+        if (tuning == 1)   // :102-126
+            hipLaunchKernelGGL((k_cont_cd<NB_>), dim3(1), dim3(64), 0, 0, (const double *)deq, K, lambda, du);
+        else               // :127-131
+            hipLaunchKernelGGL((k_level_solve<NB_>), dim3(1), dim3(64), 0, 0, (const double *)deq, (const int *)(dflag + 1), 1, K,
+                               lambda, du, dflag);
+    });
+    KCHECK();
+    HIPCHECK(hipDeviceSynchronize());
+    int flag = 0;
+    HIPCHECK(hipMemcpy(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) return fail(INSIDER_ERR_SOLVE, "the ridge system of the continuous covariate is singular to working precision");
+    HIPCHECK(hipMemcpy(updating_factor, du, (size_t)K * sizeof(double), hipMemcpyDeviceToHost));
     return INSIDER_OK;
 }
 

@@ -1789,3 +1789,4 @@ __global__ void __launch_bounds__(64) k_stats_to_dense(const double *__restrict_
 #include "insider_mm.hpp"
 #include "insider_row_merged.hpp"
 #include "insider_col_factored.hpp"
+#include "insider_cont_v2.hpp"

@@ -176,3 +176,87 @@ def attach(ds, gene_offset, rank, world, device=None, group=None, force=False, s
     if force:
         ds.set_option("force_allreduce", 1)
     return ar
+
+
+def _make_unique_id():
+    from . import _lib
+    buf = (C.c_char * _lib.COMM_ID_BYTES)()
+    _lib.check(_lib.load().insider_hip_comm_unique_id(buf, _lib.COMM_ID_BYTES))
+    return bytes(buf)
+
+
+def _vote_min(flag, group=None, cuda=True):
+    """MIN over the ranks of an integer flag (torch.distributed; the tensor lives where the backend wants it)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(flag)], dtype=torch.int32, device="cuda" if cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+def attach_voted(ds, gene_offset, rank, world, device=0, group=None, fallback="torch", log=None):
+    """`attach(mode="rccl")` for a job whose ranks must END UP ON THE SAME EXCHANGE whatever happens to one of them: the
+    in-library RCCL communicator when EVERY rank can join it, else the `fallback` mode ("torch": torch.distributed callback on
+    the library's stream; "staged": through the host) on every rank together.  ncclCommInitRank is a blocking collective: a
+    rank that failed before entering it would leave the others waiting for ever, so there are two votes (sum-MIN all-reduces
+    over torch.distributed): (1) after everything a rank does alone — shard set-up, the unique id (rank 0; its bytes travel
+    in a broadcast every rank takes part in, an empty id = rank 0 failed) — "ready to join?"; only when all are does anyone
+    call insider_hip_comm_init(); (2) after it, "joined?": a communicator that came up on some ranks only is dropped
+    everywhere (installing the callback replaces it, include/insider_hip.h).
+    INSIDER_FAIL_COMM_RANK=<r> makes rank r fail in phase 1 (rehearsal of the first vote without a broken node).
+    Returns (exchange, report): exchange = "rccl" or the callback object; report = the votes, for the bench line."""
+    import os
+    from . import _lib
+    cuda = True
+    try:
+        import torch.distributed as dist
+        cuda = dist.get_backend(group) == "nccl"
+    except Exception:
+        pass
+    report = {"attempted": "rccl", "ready_min": None, "joined_min": None, "path": None, "errors": []}
+    say = log or (lambda msg: None)
+    # ---- phase 1: what a rank does alone -----------------------------------------------------------------------------------
+    ready, uid = 1, b""
+    try:
+        if os.environ.get("INSIDER_FAIL_COMM_RANK") == str(rank):
+            raise RuntimeError(f"injected failure on rank {rank} (INSIDER_FAIL_COMM_RANK)")
+        ds.set_shard(gene_offset, rank, world, None)
+    except Exception as e:
+        ready = 0
+        report["errors"].append(f"prepare: {e!r}")
+        say(f"in-library RCCL: rank {rank} cannot prepare ({e!r})")
+    try:      # every rank takes part in the broadcast, ready or not; rank 0's failure travels as an empty id
+        if rank == 0:
+            try:
+                uid = _make_unique_id()
+            except Exception as e:
+                ready = 0
+                report["errors"].append(f"unique id: {e!r}")
+        box = [uid]
+        import torch.distributed as dist
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = box[0]
+    except Exception as e:
+        ready = 0
+        report["errors"].append(f"id broadcast: {e!r}")
+    if len(uid) != _lib.COMM_ID_BYTES:
+        ready = 0
+    report["ready_min"] = _vote_min(ready, group, cuda)
+    joined = 0
+    if report["ready_min"] == 1:
+        # ---- phase 2: the collective join ----------------------------------------------------------------------------------
+        try:
+            ds.comm_init(uid, rank, world)
+            joined = 1
+        except Exception as e:
+            report["errors"].append(f"comm_init: {e!r}")
+            say(f"in-library RCCL: rank {rank} could not join ({e!r})")
+        report["joined_min"] = _vote_min(joined, group, cuda)
+    if report["ready_min"] == 1 and report["joined_min"] == 1:
+        report["path"] = "rccl"
+        return "rccl", report
+    say(f"rank {rank}: all ranks fall back to the {fallback} exchange together (ready {report['ready_min']}, joined {report['joined_min']})")
+    ar = StagedHostAllreduce(group) if fallback == "staged" else DeviceAllreduce(device, group)
+    ds.set_shard(gene_offset, rank, world, ar)       # replaces a communicator that came up on this rank only
+    report["path"] = fallback
+    return ar, report

@@ -1,5 +1,5 @@
 # insider_hip.R — R side of the MI355X path for kai0511/insider: source() it after library(insider), or copy it into
-# the package's R/ directory in place of the two wrappers it re-points (R/RcppExports.R:8-10,20-22).
+# the package's R/ directory in place of the three wrappers it re-points (R/RcppExports.R:8-10,16-18,20-22).
 # Needs r/insider_hip_shim.c built against libinsider_hip.so (see that file's header).  Not runnable in this
 # repository's pipeline (no R in the image); the shim is compiled and executed against a stand-in for the R C API by
 # tests/test_r_shim.py, the same C ABI through ctypes by tests/test_gpu_boundary.py.
@@ -76,6 +76,17 @@ strong_coordinate_descent <- function(X, y, wstart, lambda, alpha, XtX = NULL, X
     if (is.null(res))
         res <- .Call(`_insider_strong_coordinate_descent`, X, y, wstart, lambda, alpha, XtX, Xty, tol)
     res
+}
+
+# optimize_continuous_v2(): R/RcppExports.R:16-18, the reference's eight arguments.  updating_factor is updated IN PLACE
+# (the reference's rowvec&) and nothing is returned, as there.
+optimize_continuous_v2 <- function(data, indicator, updating_factor, c_factor, updating_confd, gram, lambda, tuning, device = 0L) {
+    res <- NULL
+    if (insider_hip_available())
+        res <- .Call("insider_hip_optimize_continuous_v2_R", data, indicator, updating_factor, c_factor, updating_confd, gram, lambda, as.integer(tuning), as.integer(device))
+    if (is.null(res))
+        .Call(`_insider_optimize_continuous_v2`, data, indicator, updating_factor, c_factor, updating_confd, gram, lambda, tuning)
+    invisible(NULL)
 }
 
 # ---- .RData-free exchange with `python -m insider_amd.fit` (insider_amd/flatio.py reads / writes the same layout) ----

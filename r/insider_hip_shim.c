@@ -4,9 +4,10 @@
  * Compiled INTO the R package next to its own sources (copy this file and include/insider_hip.h to src/, add
  * `PKG_LIBS += -L$(INSIDER_HIP_DIR) -linsider_hip -Wl,-rpath,$(INSIDER_HIP_DIR)` to src/Makevars) or as a stand-alone
  * `R CMD SHLIB insider_hip_shim.c -linsider_hip` object loaded with dyn.load().  Plain R C API: needs neither Rcpp nor
- * Armadillo.  It replaces, argument for argument, the two hot-path .Call entries of the reference
+ * Armadillo.  It replaces, argument for argument, the hot-path .Call entries of the reference
  *     _insider_optimize                    (16 args)  src/RcppExports.cpp:87-110, R/RcppExports.R:20-22
  *     _insider_strong_coordinate_descent   ( 8 args)  src/RcppExports.cpp:35-50,  R/RcppExports.R:8-10
+ *     _insider_optimize_continuous_v2      ( 8 args)  src/RcppExports.cpp:69-85,  R/RcppExports.R:16-18
  * with an optional trailing `seed` (the reference draws its sweep order from R's global RNG through Rcpp::RNGScope,
  * src/RcppExports.cpp:38,90) and `device`.  R wrappers: r/insider_hip.R.
  *
@@ -357,10 +358,44 @@ SEXP insider_hip_strong_cd_R(SEXP X, SEXP y, SEXP wstart, SEXP lambda, SEXP alph
     return beta;
 }
 
+/* optimize_continuous_v2(data, indicator, updating_factor, c_factor, updating_confd, gram, lambda, tuning [, device])
+ * -> TRUE, with updating_factor updated IN PLACE (the reference's rowvec&, src/optimize.cpp:76-77; its .Call returns
+ * R_NilValue, src/RcppExports.cpp:69-85); NULL: not run here, fall back to `_insider_optimize_continuous_v2`. */
+SEXP insider_hip_optimize_continuous_v2_R(SEXP data, SEXP indicator, SEXP updating_factor, SEXP c_factor, SEXP updating_confd,
+                                          SEXP gram, SEXP lambda, SEXP tuning, SEXP device)
+{
+    if (TYPEOF(data) != REALSXP || TYPEOF(c_factor) != REALSXP || TYPEOF(updating_factor) != REALSXP ||
+        TYPEOF(updating_confd) != REALSXP)
+        Rf_error("insider_hip: data, updating_factor, c_factor and updating_confd must be numeric");
+    const int64_t n = Rf_nrows(data), p = Rf_ncols(data);
+    const int K = Rf_nrows(c_factor), tun = Rf_asInteger(tuning);
+    if (Rf_ncols(c_factor) != p || Rf_length(updating_factor) != K || Rf_length(updating_confd) != n)
+        Rf_error("insider_hip: c_factor must be K x p, updating_factor of length K, updating_confd of length n");
+    const size_t np = (size_t)n * (size_t)p;
+    const uint8_t *ind = NULL;
+    const double *g = NULL;
+    if (tun == 1) {       /* the reference reads `indicator` only here (:79-126) and `gram` only when tuning = 0 (:127-131) */
+        if ((size_t)Rf_xlength(indicator) != np) Rf_error("insider_hip: indicator shape must match data");
+        ind = mask_u8(indicator, np);
+    } else if (tun == 0) {
+        if (TYPEOF(gram) != REALSXP || Rf_nrows(gram) != K || Rf_ncols(gram) != K) Rf_error("insider_hip: gram must be numeric K x K");
+        g = REAL(gram);
+    }
+    const int rc = insider_hip_optimize_continuous_v2(REAL(data), n, p, ind, REAL(updating_factor), REAL(c_factor), K,
+                                                      REAL(updating_confd), g, Rf_asReal(lambda), tun, Rf_asInteger(device));
+    if (rc == INSIDER_ERR_UNSUPPORTED || rc == INSIDER_ERR_NO_DEVICE) {
+        Rf_warning("insider_hip (status %d): %s; using the CPU reference", rc, insider_hip_last_error());
+        return R_NilValue;
+    }
+    if (rc != INSIDER_OK) Rf_error("insider_hip (status %d): %s", rc, insider_hip_last_error());   /* an R error, never exit(1) (:133-136) */
+    return Rf_ScalarLogical(1);
+}
+
 static const R_CallMethodDef insider_hip_calls[] = {
     {"insider_hip_available_R", (DL_FUNC)&insider_hip_available_R, 0},
     {"insider_hip_optimize_R", (DL_FUNC)&insider_hip_optimize_R, 19},
     {"insider_hip_strong_cd_R", (DL_FUNC)&insider_hip_strong_cd_R, 10},
+    {"insider_hip_optimize_continuous_v2_R", (DL_FUNC)&insider_hip_optimize_continuous_v2_R, 9},
     {"insider_hip_create_R", (DL_FUNC)&insider_hip_create_R, 9},
     {"insider_hip_optimize_handle_R", (DL_FUNC)&insider_hip_optimize_handle_R, 14},
     {"insider_hip_destroy_R", (DL_FUNC)&insider_hip_destroy_R, 1},

@@ -174,3 +174,145 @@ def test_grid_parallel_tune_matches_serial():
         assert r[2] == serial[2]
         np.testing.assert_allclose(r[3], serial[3], rtol=1e-13)
     assert serial[3].shape == (6, 4) and serial[1].shape == (3, 3)
+
+
+# ---- tune(concurrent=k): the host logic around the clones, with the device fit stubbed out ---------------------------------
+class _FakeHandle(_FakeData):
+    def __init__(self, src=None):
+        self._h = 1
+        self._options = dict(src._options) if src is not None else {}
+        self.fits = 0
+
+    def clone(self):
+        return _FakeHandle(self)
+
+    def set_option(self, name, value):
+        self._options[name] = float(value)
+
+    def optimize(self, *a, **kw):
+        self.fits += 1
+        return super().optimize(*a, **kw)
+
+    def profile(self):
+        return dict(wall_ms=0.0)
+
+    def close(self):
+        self._h = None
+
+
+def _concurrent_obj():
+    from insider_amd import api
+    obj = api.Insider(params=dict(global_tol=1e-9, sub_tol=1e-5, tuning_iter=3, max_iter=5), inc_continuous=0,
+                      confounder=workloads.cyclic_levels(12, (3, 2)), data=np.zeros((12, 9)), seed=1)
+    obj["_resident_tune"] = _FakeHandle()
+    return obj
+
+
+def test_concurrent_tune_host_logic_survives_a_failing_producer_and_closed_clones(monkeypatch):
+    """(i) an exception while drawing the inits must end tune(concurrent=k) with that exception, not leave the
+    workers blocked on the queue for ever; (ii) clones closed since the last call (bench.py closes them) are not re-used;
+    (iii) options set on the data set after the clones were made reach them."""
+    import threading
+    from insider_amd import api
+    grid = dict(latent_dimension=np.array([3]), lambda_=[1.0, 2.0, 3.0], alpha=[0.1, 0.2])
+    obj = _concurrent_obj()
+    serial = api.tune(obj, rng=np.random.default_rng(5), **grid)["reg_tuning"]
+    conc = api.tune(obj, rng=np.random.default_rng(5), concurrent=3, **grid)["reg_tuning"]
+    np.testing.assert_array_equal(conc, serial)
+    clones = list(obj["_tune_clones"])
+    assert len(clones) == 2 and obj["_resident_tune"].fits + sum(c.fits for c in clones) == 12   # 6 serial + 6 dealt over the handles
+    # (ii) + (iii)
+    clones[0].close()
+    obj["_resident_tune"].set_option("cd_pass1", 128)
+    again = api.tune(obj, rng=np.random.default_rng(5), concurrent=3, **grid)["reg_tuning"]
+    np.testing.assert_array_equal(again, serial)
+    assert clones[0] not in obj["_tune_clones"] and len(obj["_tune_clones"]) == 2
+    assert all(c._h and c._options.get("cd_pass1") == 128.0 for c in obj["_tune_clones"])
+    # (i): the third draw raises
+    calls = {"n": 0}
+    real = api._fresh_inits
+
+    def failing(*a, **kw):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise MemoryError("no room for the inits")
+        return real(*a, **kw)
+
+    monkeypatch.setattr(api, "_fresh_inits", failing)
+    box = {}
+
+    def run():
+        try:
+            api.tune(obj, rng=np.random.default_rng(5), concurrent=2, **grid)
+            box["out"] = "returned"
+        except BaseException as e:
+            box["out"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout=60)
+    assert not t.is_alive(), "tune(concurrent=2) hangs when the producer of the inits fails"
+    assert isinstance(box["out"], MemoryError)
+
+
+# ---- the exchange vote of a multi-rank job (insider_amd/dist.py:attach_voted), world_size 2 over gloo --------------------------
+class _VoteHandle:
+    """Records what attach_voted does to a handle; comm_init fails on the ranks listed in `bad_join`."""
+
+    def __init__(self, rank, bad_join=()):
+        self.rank, self.bad_join, self.log = rank, bad_join, []
+
+    def set_shard(self, gene_offset, rank, world, allreduce=None):
+        self.log.append(("set_shard", type(allreduce).__name__))
+
+    def comm_init(self, uid, rank, world):
+        self.log.append(("comm_init", len(uid)))
+        if rank in self.bad_join:
+            raise RuntimeError("join failed")
+
+
+def _vote_worker(rank, world, port, case, q):
+    import torch.distributed as dist
+    from insider_amd import _lib, dist as idist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("INSIDER_FAIL_COMM_RANK", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        idist._make_unique_id = lambda: b"\x07" * _lib.COMM_ID_BYTES if case != "no_id" else (_ for _ in ()).throw(RuntimeError("no id"))
+        if case == "prepare_fails_on_1":
+            os.environ["INSIDER_FAIL_COMM_RANK"] = "1"
+        ds = _VoteHandle(rank, bad_join=(1,) if case == "join_fails_on_1" else ())
+        ex, rep = idist.attach_voted(ds, 100 * rank, rank, world, fallback="staged")
+        q.put((rank, ex if isinstance(ex, str) else type(ex).__name__, rep, ds.log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["all_join", "prepare_fails_on_1", "join_fails_on_1", "no_id"])
+def test_exchange_vote_keeps_all_ranks_on_one_path(case):
+    """the first real multi-GPU run must not die (or hang) in glue.  Whatever one rank suffers, all ranks
+    end on the same exchange; a rank that could not prepare keeps every rank out of the blocking join."""
+    ctx = mp.get_context("spawn")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_vote_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    paths = {o[1] for o in outs}
+    assert len(paths) == 1, outs                                   # every rank on the same exchange
+    joins = [sum(1 for e in o[3] if e[0] == "comm_init") for o in outs]
+    if case == "all_join":
+        assert paths == {"rccl"} and joins == [1, 1] and all(o[2]["ready_min"] == 1 and o[2]["joined_min"] == 1 for o in outs)
+    elif case == "join_fails_on_1":
+        assert paths == {"StagedHostAllreduce"} and joins == [1, 1] and all(o[2]["joined_min"] == 0 for o in outs)
+        assert all(o[3][-1] == ("set_shard", "StagedHostAllreduce") for o in outs)     # the half-made communicator is replaced
+    else:
+        assert paths == {"StagedHostAllreduce"} and joins == [0, 0]                    # nobody entered the blocking join
+        assert all(o[2]["ready_min"] == 0 and o[2]["joined_min"] is None and o[2]["path"] == "staged" for o in outs)

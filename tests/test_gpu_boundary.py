@@ -1,6 +1,6 @@
 """The drop-in boundary itself (include/insider_hip.h), called through ctypes the way r/insider_hip_shim.c calls it:
-the one-shot symbols that replace .Call(`_insider_optimize`) and .Call(`_insider_strong_coordinate_descent`), the
-general route of solve(..., likely_sympd), error paths that must leave a handle usable.  All against the CPU oracle."""
+the one-shot symbols that replace .Call(`_insider_optimize`), .Call(`_insider_strong_coordinate_descent`) and
+.Call(`_insider_optimize_continuous_v2`), the general route of solve(..., likely_sympd), error paths that must leave a handle usable.  All against the CPU oracle."""
 import ctypes as C
 
 import numpy as np
@@ -122,6 +122,58 @@ def test_strong_cd_from_design_matrix_and_outcome(oracle, K, m):
         assert np.array_equal(beta == 0, ref == 0) and abs(sw - ref_sw) <= 1
     with pytest.raises(_lib.InsiderError):
         api.strong_coordinate_descent(None, None, w0, lam, alpha)
+
+
+@pytest.mark.parametrize("tuning", [1, 0])
+@pytest.mark.parametrize("n,p,K", [(37, 50, 1), (120, 333, 7), (2000, 600, 30), (300, 129, 40), (64, 64, 63)])
+def test_optimize_continuous_v2_symbol_matches_oracle(oracle, n, p, K, tuning):
+    """.Call(`_insider_optimize_continuous_v2`)'s eight arguments (src/RcppExports.cpp:69-85) on an ARBITRARY data matrix,
+    through the raw symbol: the cyclic scalar passes on the masked residual (tuning = 1, src/optimize.cpp:79-126; an update
+    enters the next coordinate's step, and the loop ends on sum |du| < 0.1, so the iterate is compared after the same number
+    of passes) and the one ridge solve from the caller's `gram` (tuning = 0, :127-131)."""
+    rng = np.random.default_rng(1000 * K + n + tuning)
+    Cm = np.asfortranarray(rng.standard_normal((K, p)) * 0.4)
+    z = rng.standard_normal(n)
+    u_true = rng.standard_normal(K)
+    D = np.asfortranarray(np.outer(z, u_true @ Cm) + 0.3 * rng.standard_normal((n, p)))     # a signal the update has to find
+    M = np.asfortranarray(rng.random((n, p)) > 0.1, dtype=np.uint8)
+    M[:, 0] = 1                                                      # a gene with no held-out entry
+    M[0, :] = 0                                                      # a sample that is held out everywhere
+    gram = np.asfortranarray(Cm @ Cm.T) * (1.0 if tuning == 1 else 1.3)   # tuning = 0 reads the CALLER's gram, whatever it holds
+    u0 = rng.standard_normal(K) * 0.05
+    lam = 2.5
+    ref = oracle.optimize_continuous(D, M, u0, Cm, z, gram, lam, tuning=tuning)
+    lib = _lib.load()
+    dp, u8 = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    u = u0.copy()
+    rc = lib.insider_hip_optimize_continuous_v2(D.ctypes.data_as(dp), n, p, M.ctypes.data_as(u8) if tuning == 1 else None,
+                                                u.ctypes.data_as(dp), Cm.ctypes.data_as(dp), K, z.ctypes.data_as(dp),
+                                                gram.ctypes.data_as(dp) if tuning == 0 else None, lam, tuning, 0)
+    assert rc == _lib.OK, lib.insider_hip_last_error()
+    assert relerr(u, ref) < 1e-9 and not np.allclose(u, u0)
+    # the Python mirror of R/RcppExports.R:16-18 is the same call and updates its float64 argument in place (rowvec&)
+    u2 = u0.copy()
+    got = api.optimize_continuous_v2(D, M, u2, Cm, z, gram, lam, tuning)
+    assert np.array_equal(got, u) and np.array_equal(u2, u)
+
+
+def test_optimize_continuous_v2_argument_errors():
+    """Bad `tuning` is a status (the reference prints and exit(1)s, src/optimize.cpp:133-136), as are missing operands."""
+    lib = _lib.load()
+    dp, u8 = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    D, M = np.zeros((4, 5), order="F"), np.ones((4, 5), dtype=np.uint8, order="F")
+    Cm, z, u, g = np.ones((2, 5), order="F"), np.ones(4), np.zeros(2), np.eye(2)
+    args = lambda tun, ind=M, gram=g, K=2: (D.ctypes.data_as(dp), 4, 5, ind.ctypes.data_as(u8) if ind is not None else None,
+                                            u.ctypes.data_as(dp), Cm.ctypes.data_as(dp), K, z.ctypes.data_as(dp),
+                                            gram.ctypes.data_as(dp) if gram is not None else None, 1.0, tun, 0)
+    assert lib.insider_hip_optimize_continuous_v2(*args(2)) == _lib.ERR_ARG
+    assert b"tuning should be either 0 or 1" in lib.insider_hip_last_error()
+    assert lib.insider_hip_optimize_continuous_v2(*args(1, ind=None)) == _lib.ERR_ARG
+    assert lib.insider_hip_optimize_continuous_v2(*args(0, gram=None)) == _lib.ERR_ARG
+    assert lib.insider_hip_optimize_continuous_v2(*args(1, K=64)) == _lib.ERR_UNSUPPORTED
+    assert np.array_equal(u, np.zeros(2))                            # nothing was computed
+    with pytest.raises(_lib.InsiderError):
+        api.optimize_continuous_v2(D, M, u, Cm, z, g, 1.0, 3)
 
 
 def test_solve_likely_sympd_routes(oracle):

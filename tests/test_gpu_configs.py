@@ -1,6 +1,6 @@
 """GPU parity at the sizes and structures BASELINE.json's configs name (c1..c5), through the C ABI.
 
-* c3 / c5 STRUCTURE at full n: a gene slab (all samples, every level of every covariate, the real K, the real
+* c2 / c3 / c5 STRUCTURE at full n: a gene slab (all samples, every level of every covariate, the real K, the real
   held-out fraction) against the CPU oracle — one outer iteration from a non-trivial start and 11 iterations from
   the N(0, 1e-6) inits, on each of the three statistic paths.  The sweep cap (max_sweeps, honoured identically by
   the HIP path and the oracle) bounds the oracle's residual-form CD to seconds.
@@ -73,6 +73,13 @@ def c5_slab():
     s["ds"].close()
 
 
+@pytest.fixture(scope="module")
+def c2_slab():
+    s = _slab("c2")
+    yield s
+    s["ds"].close()
+
+
 def _check_slab(s, paths, expect_levels):
     w, ds = s["w"], s["ds"]
     assert w.n == workloads.CONFIGS[w.name][0] and list(w.n_levels) == expect_levels and w.K == workloads.CONFIGS[w.name][4]
@@ -109,6 +116,13 @@ def test_c3_structure_full_n_slab_vs_oracle(c3_slab, paths):
 def test_c5_structure_full_n_slab_vs_oracle(c5_slab, paths):
     """n = 5000, 3 covariates + interaction(1, 2) = 200 levels inserted second (R/insider.R:34-40), K = 25."""
     _check_slab(c5_slab, paths, [20, 200, 10, 25])
+
+
+@pytest.mark.parametrize("paths", list(PATHS))
+def test_c2_structure_full_n_slab_vs_oracle(c2_slab, paths):
+    """BASELINE config 2's own structure: n = 2000 samples, 50 x 5 levels, K = 20 (the four-waves-per-SIMD instantiation of
+    the sweep kernel, KMAX = 20; 2 x 2 MFMA blocks with 11 padding coordinates), 10 % held out."""
+    _check_slab(c2_slab, paths, [50, 5])
 
 
 def test_c3_structure_deep_sweeps_vs_oracle():

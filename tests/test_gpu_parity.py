@@ -721,6 +721,31 @@ def test_optimize_with_continuous_covariates(oracle, kw, m):
     assert relerr(got["column_factor"], ref["column_factor"]) < 1e-6
 
 
+@pytest.mark.parametrize("L", [700, 830, 1200])
+def test_many_level_covariate_with_continuous_column_vs_oracle(oracle, L):
+    """A covariate with so many levels that k_gene_u_cnt's per-wave LDS record (V row + level sums + partials, four waves per
+    block) does not fit 64 KB (from about 770 levels on), together with a continuous covariate: the merged row update may
+    then not fall back to k_gene_u, which knows nothing of the continuous columns' term z_r' A_c c_j — the data set has to
+    take the per-sample path as a whole (decided at insider_hip_create_ex).  L = 700 still runs the merged form."""
+    w = workloads.small(n=2 * L + 40, p=48, level_counts=(L, 3), K=4)
+    rng = np.random.default_rng(L)
+    Z = np.asfortranarray(rng.standard_normal((w.n, 1)))
+    U0 = np.asfortranarray(rng.normal(0.0, 0.001, size=(1, w.K)))
+    ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
+    ds.set_option("profile", 1)
+    A, C = _cp(w)
+    got = ds.optimize(A + [U0.copy(order="F")], C, w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=10, seed=5, inc_continuous=1)
+    merged = ds.profile()["row_merged"]
+    ds.close()
+    assert merged == (L == 700)
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + [U0], w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                          max_iter=10, seed=5, ctns=Z)
+    np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-8, equal_nan=True)
+    for i, a in enumerate(ref["row_matrices"]):
+        assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-6, i
+    assert relerr(got["column_factor"], ref["column_factor"]) < 1e-6
+
+
 def test_operator_level_optimize_with_ctns(oracle):
     # the reference's 16-argument optimize() with inc_continuous = 1 (R/RcppExports.R:20-22)
     w = workloads.small(n=50, p=60)

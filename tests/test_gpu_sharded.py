@@ -165,6 +165,69 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
         assert key in two and two["roofline"]["frac"] <= 1.0
 
 
+def test_bench_exchange_vote_rehearsal_one_rank_cannot_join():
+    """`bench.py --gpus 2` with the in-library RCCL exchange ATTEMPTED (INSIDER_BENCH_REHEARSE_VOTE=1) and rank 1 made to fail
+    before the join (INSIDER_FAIL_COMM_RANK=1): every rank must take the fall-back exchange TOGETHER — nobody enters the
+    blocking ncclCommInitRank — and the job finishes with the single-process loss.  (Two ranks on the one GPU: the fall-back
+    there is the host-staged exchange; on a multi-GPU node it is the torch.distributed callback, same vote.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "c2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(INSIDER_BENCH_ONE_GPU="1", INSIDER_BENCH_REHEARSE_VOTE="1", INSIDER_FAIL_COMM_RANK="1")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *common],
+                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    vote = two["config"]["exchange_vote"]
+    assert vote["attempted"] == "rccl" and vote["ready_min"] == 0 and vote["joined_min"] is None and vote["path"] == "staged", vote
+    assert "StagedHostAllreduce" in two["config"]["parallelism"]
+    assert "fall back to the staged exchange together" in r2.stderr and "injected failure on rank 1" in r2.stderr
+    env1 = {k: v for k, v in env.items() if not k.startswith("INSIDER_")}
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], cwd=root, env=env1, capture_output=True, text=True,
+                        timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["loss"] == pytest.approx(one["loss"], rel=1e-10)
+
+
+@pytest.mark.multi_gpu
+@pytest.mark.parametrize("fail_rank", [None, 1])
+def test_bench_gpus_2_rccl_on_two_gpus(fail_rank):
+    """`python bench.py --gpus 2` as the driver launches it on a multi-GPU node: the in-library RCCL exchange (both votes 1,
+    exchange "rccl"), and with one rank kept from joining, the torch.distributed callback on both ranks; the sharded
+    problem's loss equals the single-GPU run's either way."""
+    from insider_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "c2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK") and not k.startswith("INSIDER_")}
+    if fail_rank is not None:
+        env["INSIDER_FAIL_COMM_RANK"] = str(fail_rank)
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *common], cwd=root, env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    vote = two["config"]["exchange_vote"]
+    if fail_rank is None:
+        assert vote["ready_min"] == 1 and vote["joined_min"] == 1 and vote["path"] == "rccl", vote
+        assert "exchange: rccl" in two["config"]["parallelism"]
+    else:
+        assert vote["ready_min"] == 0 and vote["path"] == "torch" and "DeviceAllreduce" in two["config"]["parallelism"], vote
+    env.pop("INSIDER_FAIL_COMM_RANK", None)
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], cwd=root, env=env, capture_output=True, text=True,
+                        timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["loss"] == pytest.approx(one["loss"], rel=1e-10)
+
+
 def test_bench_grid_parallel_rehearsal_on_one_gpu():
     """`bench.py --gpus 2 --grid`: config 3's 40 grid points dealt over the ranks (every rank keeps the whole c3 data set
     resident, api.tune(rank, world), one all-reduce of the result table), reported as the `grid_parallel` block next to the

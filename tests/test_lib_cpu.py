@@ -21,7 +21,7 @@ def lib():
 
 def test_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "insider_hip.h")).read()
-    declared = set(re.findall(r"\b(insider_hip_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(insider_hip_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert getattr(lib, s) is not None

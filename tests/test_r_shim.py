@@ -96,6 +96,7 @@ def test_shim_compiles_warning_free_against_the_r_api_stand_in():
 
 def test_registered_routines_match_the_r_wrappers(shim):
     arities = {"insider_hip_available_R": 0, "insider_hip_optimize_R": 19, "insider_hip_strong_cd_R": 10,
+               "insider_hip_optimize_continuous_v2_R": 9,
                "insider_hip_create_R": 9, "insider_hip_optimize_handle_R": 14, "insider_hip_destroy_R": 1,
                "insider_hip_cache_clear_R": 0, "insider_hip_cache_stats_R": 0}
     for name, n in arities.items():
@@ -246,3 +247,29 @@ def test_explicit_handle_lifecycle(shim):
     assert shim.mock_finalized_count() == n0 + 1
     with pytest.raises(RuntimeError, match="destroyed"):
         r.call("insider_hip_optimize_handle_R", h2, *args)
+
+
+@pytest.mark.gpu
+def test_optimize_continuous_v2_through_the_shim_updates_in_place(shim):
+    """The reference's eight arguments (R/RcppExports.R:16-18): the K-vector is updated in place (rowvec&), the routine's
+    result equals the ctypes path bit for bit, for both `tuning` values."""
+    from insider_amd import api
+    r = R(shim)
+    rng = np.random.default_rng(21)
+    n, p, K = 60, 90, 7
+    D = np.asfortranarray(rng.standard_normal((n, p)))
+    M = np.asfortranarray(rng.random((n, p)) > 0.15, dtype=np.int32)
+    Cm = np.asfortranarray(rng.standard_normal((K, p)) * 0.3)
+    z = rng.standard_normal(n)
+    u0 = rng.standard_normal(K) * 0.1
+    gram = np.asfortranarray(Cm @ Cm.T)
+    for tuning in (1, 0):
+        u = r.real(u0.copy())
+        out = r.call("insider_hip_optimize_continuous_v2_R", r.real(D), r.integer(M), u, r.real(Cm), r.real(z), r.real(gram),
+                     r.scalar(1.5), r.scalar(tuning), r.scalar(0))
+        assert not shim.mock_is_nil(out)
+        ref = api.optimize_continuous_v2(D, M, u0.copy(), Cm, z, gram, 1.5, tuning)
+        assert np.array_equal(r.to_numpy(u, (K,)), ref) and not np.array_equal(ref, u0)
+    with pytest.raises(RuntimeError, match="tuning should be either 0 or 1"):
+        r.call("insider_hip_optimize_continuous_v2_R", r.real(D), r.integer(M), r.real(u0.copy()), r.real(Cm), r.real(z), r.real(gram),
+               r.scalar(1.5), r.scalar(2), r.scalar(0))
