@@ -158,21 +158,9 @@ def cpu_baseline(name, lam, alpha, n_cores, sweeps_per_gene_iter, budget_s):
         c_oracle.set_col_chunk(100)
         c_oracle.set_cd_form(0)
     main = out["reference_threads"]
-    # the model (fixed cost per gene + cost per gene per sweep) against REAL oracle runs on a GPU box's host cores
-    # (tools/cpu_validate.py, one job per round): c2 in full, 31 iterations; a 4096-gene slab of c3, two iterations, uncapped
-    check = None
-    try:
-        mc = json.load(open(os.path.join(ROOT, "profiles", "r03", "cpu_model_check.json")))
-        check = {"source": "profiles/r03/cpu_model_check.json (tools/cpu_validate.py; RECORDED in round 3 on another box, not measured in this run)", "cpu_model": mc.get("cpu_model"),
-                 "nproc": mc.get("nproc")}
-        for key in ("c2_full", "c3_slab"):
-            if key in mc:
-                check[key] = {k: mc[key][k] for k in ("shape", "iterations", "sweeps_per_gene_per_iter", "measured_wall_s",
-                                                      "model_wall_s", "measured_over_model") if k in mc[key]}
-    except Exception:
-        pass
+    # (the model behind the extrapolation is checked in THIS run: model_check_live above; full oracle runs of earlier rounds are in
+    # profiles/r03/cpu_model_check.json, tools/cpu_validate.py)
     return {"value": main["value"], "unit": "outer-iterations/s", "cores": main["col_threads"], "kind": "port", "model_check_live": live,
-            "model_check": check,
             "sample": (f"{name}: first {genes} of {cp} genes x all {cn} samples, 1 outer iteration, sweeps capped at {cap}, "
                        f"gene-loop chunk 1; {main['sample_wall_s']:.1f} s wall, cpu-time/wall {main['cpu_over_wall']:.1f} "
                        f"(row step {main['row_threads']} / column step {main['col_threads']} threads; the reference hard-codes "
@@ -437,8 +425,9 @@ def main():
                     # valid only for the library it was measured on: compared with the hash the LOADED library reports
                     same = tj.get("source_sha") == lib_sha
                     traffic = ent if same else {}
-                    tnote = (f"rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, {tj.get('command', '?')}); FETCH x 2 per "
-                             f"MI355X_MICROARCH.md; taken on source_sha {tj.get('source_sha')} (commit {tj.get('commit', '?')}), "
+                    # (the entry's OWN command and commit; files of round 4 carried one top-level pair)
+                    tnote = (f"rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, {ent.get('command') or tj.get('command', '?')}); FETCH x 2 per "
+                             f"MI355X_MICROARCH.md; taken on source_sha {tj.get('source_sha')} (commit {ent.get('commit') or tj.get('commit', '?')}), "
                              + ("the sources of the library that ran here" if same else
                                 f"NOT the library that ran here ({lib_sha}): traffic withheld (null)"))
             except Exception as e:
@@ -455,7 +444,8 @@ def main():
                 if pmc_key in ij:
                     if ij.get("source_sha") == lib_sha:
                         issue = ij[pmc_key]
-                        inote = f"rocprofv3 --pmc SQ_* passes ({ij.get('command', '?')}), source_sha {ij.get('source_sha')} = the library that ran here"
+                        inote = (f"rocprofv3 --pmc SQ_* passes ({issue.get('command') or 'command not recorded for this entry'}; commit "
+                                 f"{issue.get('commit') or 'not recorded'}), source_sha {ij.get('source_sha')} = the library that ran here")
                     else:
                         inote = f"profiles/issue.json was taken on source_sha {ij.get('source_sha')}, not on the library that ran here ({lib_sha}): withheld"
             except Exception as e:

@@ -136,7 +136,9 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * "list_fine" (1, default = the per-entry statistics kernel uses the 4x4x4 form of the f64 matrix instruction for 16 <= K <= 31
  * [fewer wasted outputs than 16 x 16 blocks], 0 = the 16x16x4 form; same sums in another order), "row_gemm" / "row_gemm_waves" (1, default = the per-level weighted Gram sums of a covariate with >= 49
  * levels come from one GEMM over genes, cut into row_gemm_waves [1024] waves; 0 = one weighted rank-one update per (level, gene);
- * same sums in another order, results agree to rounding), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
+ * same sums in another order, results agree to rounding), "cd_pairs" (1, default = the register-resident sweep kernel [K <= 30] is routed through its blocks of TWO
+ * coordinate steps wherever two consecutive coordinates of a sweep's order share a coordinate slot: a third fewer computed jumps,
+ * the same steps in the same order — bit-identical iterates; 0 = one step per block), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
  * cd_cold_iters outer iterations of a call [default 3]: the register-resident sweep kernel stops at sweep cd_pass1 [64; 0 = one
  * pass], cd_pass1 x ratio [4], ..., re-packing the genes still running by their estimated remaining length between passes;
  * the iterates are bit-identical to the single-pass solve). */
@@ -282,7 +284,7 @@ int insider_hip_get_info(insider_hip_handle *h, const char *name, double *out);
 
 /* Diagnostics: copy an internal per-gene array to the host: "cd_pass_slot" (uint32 x p: what the last limited pass of a
  * multi-pass column solve left per gene: 0xFFFFFFFF = finished, else estimate bucket << 24 | rank), "gene_perm" (int32 x p:
- * the launch order), "order_table" (the sweep-order table of the last column solve: rows of 320 bytes, one per sweep of the
+ * the launch order), "order_table" (the sweep-order table of the last column solve: rows of 448 bytes, one per sweep of the
  * period; bytes 0..K-1 of row s = the coordinates of sweep s in visiting order, include/insider_perm.h). */
 int insider_hip_get_array(insider_hip_handle *h, const char *name, void *out, int64_t bytes);
 

@@ -54,6 +54,11 @@ class InsiderData:
                                              _lib.ptr(n_levels, C.c_int32), zp, self.m, _lib.ptr(Mtr, C.c_uint8),
                                              _lib.ptr(Mte, C.c_uint8), int(device), C.byref(self._h)))
         self._cb = None  # keeps the ctypes callback alive
+        # measurement knob: INSIDER_HIP_OPTIONS="name=value,name=value" applies library options to every handle this process
+        # creates (A/B of an option through tools that do not expose it)
+        for kv in filter(None, os.environ.get("INSIDER_HIP_OPTIONS", "").split(",")):
+            name, value = kv.split("=")
+            self.set_option(name.strip(), float(value))
 
     def clone(self):
         """Another handle on the SAME resident data set (insider_hip_clone): the device copy of X, the lists and the
@@ -531,6 +536,11 @@ def tune(obj, latent_dimension=None, lambda_=0.1, alpha=0.0, out_dir=None, rng=N
     this rank has already finished instead of from its fresh draw (which is still drawn, so the generator state — and
     every point that does start cold — is unchanged).  The first outer iterations of a cold fit run thousands of
     coordinate sweeps per gene to leave the near-zero inits; a neighbouring optimum is a few hundred sweeps away.
+    IT CHANGES THE ANSWER, not only the time: a tuning_iter = 30 fit is not converged, so a fit that starts near a
+    neighbour's optimum ends elsewhere than the cold fit of the same point, and the grid's argmin may move.  Measured
+    (profiles/r04/grid_c3_k2.json, grid_c2_k4.json): the selected (lambda, alpha) DIFFERED from the cold grid's at config 3
+    and at config 2 (`best_point_agrees_with_cold` false in both; largest test-RMSE difference over the 40 points 2.4e-5
+    and 4e-4).  Use it to explore a grid quickly; re-run the chosen neighbourhood cold before reporting a selection.
 
     ``rank`` / ``world``: grid-parallel tuning across the GPUs of a node: every rank keeps the
     whole data set resident, grid point g is fitted by rank g % world and the result tables are summed over

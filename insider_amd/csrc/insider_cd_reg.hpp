@@ -23,7 +23,7 @@ namespace insider {
 
 constexpr int REG_ORDER_OFF = 128;   // byte offset of the block-offset dwords inside an order-table row
 constexpr int REG3_ORDER_OFF = 124;  // ... for 32 < K <= 48 (three slots): one dword earlier, so that 1 + 48 dwords fit the row
-static_assert(ORDER_ROW == 0x140, "the sweep prologue prefetches the next row at +0x140");
+static_assert(ORDER_ROW == INSIDER_ORDER_ROW && REG_ORDER_OFF + 8 * 33 <= ORDER_ROW, "a row holds 1 + 32 successor pairs behind the order bytes");
 constexpr int REG_BLOCK = INSIDER_REG_BLOCK;   // bytes between the code blocks of consecutive coordinates (see REG_BLOCK_HEAD)
 #define REG_STR_(x) #x
 #define REG_STR(x) REG_STR_(x)
@@ -63,45 +63,138 @@ struct RegState {
 // DPP fmac on a lane indicator (no exec writes: slower, 2.17-2.24 ms — four more full-width fp64 instructions per step
 // cost more clock than the two exec writes cost issue slots); wave priorities by hardware wave id (slower); the exec
 // narrowing after the clamp (slower); other positions of the add (equal).
-#define REG_BLOCK_HEAD(KK, HS, BS, IS, IT)                       \
-    REG_ORG(KK)                                                  \
+#define REG_BLOCK_HEAD(KK, HS, BS, IS, IT) REG_ORG(KK) REG_STEP_HEAD(HS, BS, IS, IT)
+#define REG_STEP_HEAD(HS, BS, IS, IT)                            \
     "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
     "v_max_f64 %[dn], %[" HS "], %[" HS "] clamp\n"              \
-    "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
     "v_add_f64 %[dn], %[" HS "], -%[dn]\n"                       \
     "v_fma_f64 %[dn], -%[dn], %[" IS "], %[" BS "]\n"            \
     "v_fmac_f64 %[" BS "], -1.0, %[dn]\n"                        \
     "s_mov_b64 exec, -1\n"
-#define REG_JUMP "s_setpc_b64 vcc\n"
+// Round 5: the successor list holds ABSOLUTE code addresses as (lo, hi) dword pairs — entry e (0 = the sweep's first block,
+// 1 + k = the block visited after coordinate k) sits in the aligned scalar pair s[REG_PB + 2 e : REG_PB + 2 e + 1], REG_PB =
+// 96 - 2 KMAX (KMAX <= 30; KMAX = 32 keeps offsets, see REGO_HEAD), loaded straight from the order-table row — so a block ends in `s_setpc_b64` on its own pair: no address add per
+// step (one of the step's ten instructions), no s_getpc / add / addc / mov per sweep, no vcc, and no alignment demand on the
+// table of blocks.  The table's address reaches k_order_table from a probe launch of the kernel itself (reg_code_base below).
+#define REG_PB REG_STR(REG_PBN)
+#define REG_JUMP(KK) "s_setpc_b64 s[" REG_PB "+2+2*" #KK ":" REG_PB "+3+2*" #KK "]\n"
 #define REG_ORG(KK) ".org Lc%= + " REG_STR(INSIDER_REG_BLOCK) "*" #KK "\n"
-#define REG_ALIGN "s_setpc_b64 vcc\n.p2align 12\n"
 #define REG_FMAC(H, GK, IT) "v_fmac_f64_dpp %[" H "], %[dn], %[" GK "] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n"
 #define REG_BLOCK2_LO(KK) \
-    REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) REG_JUMP
+    REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) REG_JUMP(KK)
 #define REG_BLOCK2_HI(KK, IT) \
-    REG_BLOCK_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) REG_JUMP
-#define REG_BLOCK1(KK) REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_JUMP
-#define REG_PROLOGUE                               \
-    "s_load_dwordx16 s[64:79], %[tb], 0x0\n"       \
-    "s_load_dwordx16 s[80:95], %[tb], 0x40\n"      \
-    "s_load_dwordx2 s[96:97], %[tb], 0x80\n"       \
-    "s_getpc_b64 s[98:99]\n"                       \
-    "Lr%=:\n"                                      \
-    "s_add_u32 s98, s98, Lc%=-Lr%=\n"              \
-    "s_addc_u32 s99, s99, 0\n"                     \
-    "s_mov_b32 vcc_hi, s99\n"                      \
-    "s_waitcnt lgkmcnt(0)\n"                       \
-    "s_load_dword %[sk], %[tb], 0x140\n"           /* touch the next sweep's row (ORDER_ROW = 0x140 further): */ \
-    "s_load_dword %[p1], %[tb], 0x180\n"           /* its three lines are in the scalar cache when that sweep */ \
-    "s_load_dword %[p2], %[tb], 0x1c0\n"           /* starts; waited for in the exit block                    */ \
-    "s_add_u32 vcc_lo, s64, s98\n"                 \
-    REG_ALIGN                                      \
+    REG_BLOCK_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) REG_JUMP(KK)
+#define REG_BLOCK1(KK) REG_BLOCK_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_JUMP(KK)
+// ---- blocks of TWO coordinate steps (round 5) -----------------------------------------------------------------------------
+// A launch whose waves are mostly alone on their SIMDs (few genes, or the tail of the longest genes) is bound by ONE wave's
+// step: its instructions at one per ~6 cycles plus the ~28 cycles an instruction buffer takes to refill behind the computed
+// jump.  Where two consecutive coordinates of a sweep's order belong to the same coordinate slot, k_order_table can route the
+// sweep through a block that steps both — the same instructions in the same order, so the iterates do not change — and a sweep
+// takes ~20 jumps instead of 30.  With static operands there is one block per ordered pair of a slot: 16 x 16 + W x W of them
+// (W = KMAX - 16; the a == b slots are never visited), 128 bytes apart, pair (a, b) of slot 0 at index 16 a + b, of slot 1 at
+// 256 + W (a - 16) + (b - 16).  With absolute successor addresses they need neither a place inside the loop body nor an
+// alignment: they sit in a section of their own behind a named label (reg_pair_base), so the sweep loop stays as compact as
+// without them (round 4's in-line table of offsets cost 3.7 % in loop overheads and won back 1.9 %), and the
+// ROUTING is a property of the order table: option "cd_pairs" decides per call whether sweeps go through them.
+// (One LINE per step: the compiler's branch relaxation prices an asm statement at 20 bytes per line, and 452 blocks of 18 lines
+// would make it turn the sweep loop's back edge into a four-instruction long branch.  The step is therefore an ASSEMBLER macro,
+// defined inside the statement that uses it (every inline-asm statement is assembled by a parser of its own) and purged at its
+// end — the same eight instructions as REG_STEP_HEAD + two REG_FMAC; a one-slot step has no second fmac.)
+#define REG_STEP_MACROS                                                \
+    ".macro INSIDER_CD_STEP2 it, h, b, i, lm, dn, h0, h1, g0, g1\n"    \
+    "s_lshl_b64 exec, \\lm, \\it\n"                                    \
+    "v_max_f64 \\dn, \\h, \\h clamp\n"                                \
+    "v_add_f64 \\dn, \\h, -\\dn\n"                                    \
+    "v_fma_f64 \\dn, -\\dn, \\i, \\b\n"                              \
+    "v_fmac_f64 \\b, -1.0, \\dn\n"                                    \
+    "s_mov_b64 exec, -1\n"                                             \
+    "v_fmac_f64_dpp \\h0, \\dn, \\g0 row_newbcast:\\it row_mask:0xf bank_mask:0xf\n" \
+    "v_fmac_f64_dpp \\h1, \\dn, \\g1 row_newbcast:\\it row_mask:0xf bank_mask:0xf\n" \
+    ".endm\n"                                                          \
+    ".macro INSIDER_CD_STEP1 it, h, b, i, lm, dn, g0\n"                \
+    "s_lshl_b64 exec, \\lm, \\it\n"                                    \
+    "v_max_f64 \\dn, \\h, \\h clamp\n"                                \
+    "v_add_f64 \\dn, \\h, -\\dn\n"                                    \
+    "v_fma_f64 \\dn, -\\dn, \\i, \\b\n"                              \
+    "v_fmac_f64 \\b, -1.0, \\dn\n"                                    \
+    "s_mov_b64 exec, -1\n"                                             \
+    "v_fmac_f64_dpp \\h, \\dn, \\g0 row_newbcast:\\it row_mask:0xf bank_mask:0xf\n" \
+    ".endm\n"
+#define REG_STEP_LO(KK) "INSIDER_CD_STEP2 " #KK ", %[h0], %[b0], %[i0], %[lm], %[dn], %[h0], %[h1], %[ga" #KK "], %[gb" #KK "]\n"
+#define REG_STEP_HI(KK, IT) "INSIDER_CD_STEP2 " #IT ", %[h1], %[b1], %[i1], %[lm], %[dn], %[h0], %[h1], %[ga" #KK "], %[gb" #KK "]\n"
+#define REG_STEP1_LO(KK) "INSIDER_CD_STEP1 " #KK ", %[h0], %[b0], %[i0], %[lm], %[dn], %[ga" #KK "]\n"
+#define REGP_LO(A, B) ".p2align 7\n" REG_STEP_LO(A) REG_STEP_LO(B) REG_JUMP(B)
+#define REGP_HI(A, IA, B, IB) ".p2align 7\n" REG_STEP_HI(A, IA) REG_STEP_HI(B, IB) REG_JUMP(B)
+#define REGP1_LO(A, B) ".p2align 7\n" REG_STEP1_LO(A) REG_STEP1_LO(B) REG_JUMP(B)
+#define REG_LIST_LO2(F, A) F(A, 0) F(A, 1) F(A, 2) F(A, 3) F(A, 4) F(A, 5) F(A, 6) F(A, 7) F(A, 8) F(A, 9) F(A, 10) F(A, 11) F(A, 12) F(A, 13) F(A, 14) F(A, 15)
+#define REG_HB2_18(F, A, IA) F(A, IA, 16, 0) F(A, IA, 17, 1)
+#define REG_HB2_20(F, A, IA) REG_HB2_18(F, A, IA) F(A, IA, 18, 2) F(A, IA, 19, 3)
+#define REG_HB2_22(F, A, IA) REG_HB2_20(F, A, IA) F(A, IA, 20, 4) F(A, IA, 21, 5)
+#define REG_HB2_24(F, A, IA) REG_HB2_22(F, A, IA) F(A, IA, 22, 6) F(A, IA, 23, 7)
+#define REG_HB2_26(F, A, IA) REG_HB2_24(F, A, IA) F(A, IA, 24, 8) F(A, IA, 25, 9)
+#define REG_HB2_28(F, A, IA) REG_HB2_26(F, A, IA) F(A, IA, 26, 10) F(A, IA, 27, 11)
+#define REG_HB2_30(F, A, IA) REG_HB2_28(F, A, IA) F(A, IA, 28, 12) F(A, IA, 29, 13)
+#define REGP_ROW_LO(A) REG_LIST_LO2(REGP_LO, A)
+#define REGP1_ROW_LO(A) REG_LIST_LO2(REGP1_LO, A)
+#define REGP_ROW_HI(A, IA) REG_CAT(REG_HB2_, REG_KM)(REGP_HI, A, IA)
+// the pair blocks of an instantiation, in index order, in their own section; the label in front of them is what reg_pair_base takes
+#define REG_PAIRS_OPEN                                                                       \
+    REG_STEP_MACROS                                                                          \
+    ".pushsection .text.insider_cdpair_" REG_STR(REG_KM) ",\"ax\",@progbits\n"               \
+    ".p2align 7\n"                                                                           \
+    "insider_cdpair_" REG_STR(REG_KM) ":\n"
+#define REG_PAIRS_CLOSE ".p2align 7\n s_endpgm\n .popsection\n .purgem INSIDER_CD_STEP2\n .purgem INSIDER_CD_STEP1\n"
+// the row's pairs into s[REG_PB : 97] : 2 (KMAX + 1) dwords from byte REG_ORDER_OFF of the order-table row, in the largest aligned
+// pieces (the destination of an x4 / x8 / x16 scalar load is 4-aligned: REG_PB is a multiple of 4 for even KMAX)
+#define REG_LOADS_16 "s_load_dwordx16 s[64:79], %[tb], 0x0\n s_load_dwordx16 s[80:95], %[tb], 0x40\n s_load_dwordx2 s[96:97], %[tb], 0x80\n"
+#define REG_LOADS_18 "s_load_dwordx16 s[60:75], %[tb], 0x0\n s_load_dwordx16 s[76:91], %[tb], 0x40\n s_load_dwordx4 s[92:95], %[tb], 0x80\n s_load_dwordx2 s[96:97], %[tb], 0x90\n"
+#define REG_LOADS_20 "s_load_dwordx16 s[56:71], %[tb], 0x0\n s_load_dwordx16 s[72:87], %[tb], 0x40\n s_load_dwordx8 s[88:95], %[tb], 0x80\n s_load_dwordx2 s[96:97], %[tb], 0xa0\n"
+#define REG_LOADS_22 "s_load_dwordx16 s[52:67], %[tb], 0x0\n s_load_dwordx16 s[68:83], %[tb], 0x40\n s_load_dwordx8 s[84:91], %[tb], 0x80\n s_load_dwordx4 s[92:95], %[tb], 0xa0\n s_load_dwordx2 s[96:97], %[tb], 0xb0\n"
+#define REG_LOADS_24 "s_load_dwordx16 s[48:63], %[tb], 0x0\n s_load_dwordx16 s[64:79], %[tb], 0x40\n s_load_dwordx16 s[80:95], %[tb], 0x80\n s_load_dwordx2 s[96:97], %[tb], 0xc0\n"
+#define REG_LOADS_26 "s_load_dwordx16 s[44:59], %[tb], 0x0\n s_load_dwordx16 s[60:75], %[tb], 0x40\n s_load_dwordx16 s[76:91], %[tb], 0x80\n s_load_dwordx4 s[92:95], %[tb], 0xc0\n s_load_dwordx2 s[96:97], %[tb], 0xd0\n"
+#define REG_LOADS_28 "s_load_dwordx16 s[40:55], %[tb], 0x0\n s_load_dwordx16 s[56:71], %[tb], 0x40\n s_load_dwordx16 s[72:87], %[tb], 0x80\n s_load_dwordx8 s[88:95], %[tb], 0xc0\n s_load_dwordx2 s[96:97], %[tb], 0xe0\n"
+#define REG_LOADS_30 "s_load_dwordx16 s[36:51], %[tb], 0x0\n s_load_dwordx16 s[52:67], %[tb], 0x40\n s_load_dwordx16 s[68:83], %[tb], 0x80\n s_load_dwordx8 s[84:91], %[tb], 0xc0\n s_load_dwordx4 s[92:95], %[tb], 0xe0\n s_load_dwordx2 s[96:97], %[tb], 0xf0\n"
+#define REG_CAT_(a, b) a##b
+#define REG_CAT(a, b) REG_CAT_(a, b)
+// (the next sweep's row is touched one sweep ahead: its four 64-byte lines from REG_ORDER_OFF on are in the scalar cache when that
+// sweep starts; waited for in the exit block)
+#ifndef INSIDER_REG_TOUCHES
+#define INSIDER_REG_TOUCHES 4
+#endif
+#if INSIDER_REG_TOUCHES == 4
+#define REG_TOUCH                                                                    \
+    "s_load_dword %[sk], %[tb], " REG_STR(INSIDER_ORDER_ROW) "\n"                     \
+    "s_load_dword %[p1], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x40\n"                \
+    "s_load_dword %[p2], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x80\n"                \
+    "s_load_dword %[p3], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0xc0\n"
+#elif INSIDER_REG_TOUCHES == 2
+#define REG_TOUCH                                                                    \
+    "s_load_dword %[sk], %[tb], " REG_STR(INSIDER_ORDER_ROW) "\n"                     \
+    "s_load_dword %[p2], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x80\n"
+#else
+#define REG_TOUCH
+#endif
+#define REG_PROLOGUE                                                                 \
+    REG_CAT(REG_LOADS_, REG_KM)                                                      \
+    "s_waitcnt lgkmcnt(0)\n"                                                         \
+    REG_TOUCH                                                                        \
+    "s_setpc_b64 s[" REG_PB ":" REG_PB "+1]\n"                                        \
+    ".p2align 8\n"                                                                   \
+    "insider_cdtab_" REG_STR(REG_KM) "_%c[who]:\n"                                    \
     "Lc%=:\n"
 #define REG_EPILOGUE(NBLK) REG_ORG(NBLK) " s_waitcnt lgkmcnt(0)\n"   /* exit block */
-#define REG_CLOBBERS                                                                                                     \
-    "vcc", "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",   \
-        "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91",  \
-        "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+#define REG_S48_63 "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
+#define REG_S64_97 "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+// what an instantiation clobbers: its pair registers (the compiler keeps the sweep loop's own scalars below them)
+#define REG_CLOB_16 "scc", "memory", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOB_18 "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOB_20 "scc", "memory", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOB_22 "scc", "memory", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOB_24 "scc", "memory", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOB_26 "scc", "memory", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOB_28 "scc", "memory", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOB_30 "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
+#define REG_CLOBBERS REG_CAT(REG_CLOB_, REG_KM)
 #define REG_GA(KK) [ga##KK] "v"(G[0][KK]),
 #define REG_GB(KK) [gb##KK] "v"(G[1][KK]),
 #define REG_HI16(KK, IT) REG_BLOCK2_HI(KK, IT)
@@ -124,47 +217,188 @@ struct RegState {
 #define REG_HB_30(F) REG_HB_28(F) F(28, 12) F(29, 13)
 #define REG_HB_32(F) REG_HB_30(F) F(30, 14) F(31, 15)
 
-// tb: this sweep's block-offset dwords (order-table row + REG_ORDER_OFF)
+// tb: this sweep's successor pairs (order-table row + REG_ORDER_OFF).  WHO: which kernel the sweep is inlined into (0 = the column
+// update k_cd_cols_reg, 1 = the stand-alone batch k_cd_batch_reg): part of the NAMED label of the table of blocks, whose address
+// reg_code_base() takes from another asm statement of the same kernel
 #if defined(__HIP_DEVICE_COMPILE__)   // gfx950 assembly: hipcc's host pass must not parse it
 #define REG_DEFINE_SWEEP2(KMAX)                                                                                          \
+    template <int WHO>                                                                                                   \
     __device__ __forceinline__ void reg_sweep(RegState<2> &S, const double (&G)[2][KMAX], const uint32_t *tb)            \
     {                                                                                                                    \
         double dn;                                                                                                       \
-        int sk, p1, p2;                                                                                                  \
+        int sk, p1, p2, p3;                                                                                              \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
-        asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                       \
-                     : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]),                 \
-                       [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2)                                   \
-                     : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(      \
-                           S.tau[0]),                                                                                    \
-                       [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm)                                         \
-                     : REG_CLOBBERS);                                                                                    \
+        if constexpr (WHO == 0)                                                                                          \
+            asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                   \
+                             REG_PAIRS_OPEN REG_LIST_LO(REGP_ROW_LO) REG_HB_##KMAX(REGP_ROW_HI) REG_PAIRS_CLOSE               \
+                         : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]),             \
+                           [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3)               \
+                         : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(  \
+                               S.tau[0]),                                                                                \
+                           [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)                                \
+                         : REG_CLOBBERS);                                                                                \
+        else                                                                                                             \
+            asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                   \
+                         : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]),             \
+                           [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3)               \
+                         : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(  \
+                               S.tau[0]),                                                                                \
+                           [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)                                \
+                         : REG_CLOBBERS);                                                                                \
     }
 #else
 #define REG_DEFINE_SWEEP2(KMAX) \
+    template <int WHO>          \
     __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][KMAX], const uint32_t *) {}
 #endif
+#define REG_KM 18
+#define REG_PBN 60
 REG_DEFINE_SWEEP2(18)
+#undef REG_KM
+#undef REG_PBN
+#define REG_KM 20
+#define REG_PBN 56
 REG_DEFINE_SWEEP2(20)
+#undef REG_KM
+#undef REG_PBN
+#define REG_KM 22
+#define REG_PBN 52
 REG_DEFINE_SWEEP2(22)
+#undef REG_KM
+#undef REG_PBN
+#define REG_KM 24
+#define REG_PBN 48
 REG_DEFINE_SWEEP2(24)
+#undef REG_KM
+#undef REG_PBN
+#define REG_KM 26
+#define REG_PBN 44
 REG_DEFINE_SWEEP2(26)
+#undef REG_KM
+#undef REG_PBN
+#define REG_KM 28
+#define REG_PBN 40
 REG_DEFINE_SWEEP2(28)
+#undef REG_KM
+#undef REG_PBN
+#define REG_KM 30
+#define REG_PBN 36
 REG_DEFINE_SWEEP2(30)
-REG_DEFINE_SWEEP2(32)
+#undef REG_KM
+#undef REG_PBN
+// KMAX = 32 (K = 31, 32) keeps the successor list as 32-bit block OFFSETS: its 33 pairs would take s34 ... s99, every scalar
+// register between the reserved s32 and s100, and the kernel (168 VGPRs for 128 matrix registers) then spills a vector register
+// under the step's narrowed exec mask.  The list is loaded into s[64:97] (dword 0 = first block, dword 1 + k = the block after
+// coordinate k), each block adds the table's base address (s98; the table starts on a 4 KiB boundary and is shorter than 4 KiB,
+// so every block shares the high word, vcc_hi) to its own entry in vcc_lo while the vector chain runs, and jumps through vcc.
+#define REGO_HEAD(KK, HS, BS, IS, IT)                            \
+    REG_ORG(KK)                                                  \
+    "s_lshl_b64 exec, %[lm], " #IT "\n"                          \
+    "v_max_f64 %[dn], %[" HS "], %[" HS "] clamp\n"              \
+    "s_add_u32 vcc_lo, s[65+" #KK "], s98\n"                     \
+    "v_add_f64 %[dn], %[" HS "], -%[dn]\n"                       \
+    "v_fma_f64 %[dn], -%[dn], %[" IS "], %[" BS "]\n"            \
+    "v_fmac_f64 %[" BS "], -1.0, %[dn]\n"                        \
+    "s_mov_b64 exec, -1\n"
+#define REGO_LO(KK) REGO_HEAD(KK, "h0", "b0", "i0", KK) REG_FMAC("h0", "ga" #KK, KK) REG_FMAC("h1", "gb" #KK, KK) "s_setpc_b64 vcc\n"
+#define REGO_HI(KK, IT) REGO_HEAD(KK, "h1", "b1", "i1", IT) REG_FMAC("h0", "ga" #KK, IT) REG_FMAC("h1", "gb" #KK, IT) "s_setpc_b64 vcc\n"
+#define REGO_PROLOGUE                              \
+    "s_load_dwordx16 s[64:79], %[tb], 0x0\n"       \
+    "s_load_dwordx16 s[80:95], %[tb], 0x40\n"      \
+    "s_load_dwordx2 s[96:97], %[tb], 0x80\n"       \
+    "s_getpc_b64 s[98:99]\n"                       \
+    "Lr%=:\n"                                      \
+    "s_add_u32 s98, s98, Lc%=-Lr%=\n"              \
+    "s_addc_u32 s99, s99, 0\n"                     \
+    "s_mov_b32 vcc_hi, s99\n"                      \
+    "s_waitcnt lgkmcnt(0)\n"                       \
+    "s_load_dword %[sk], %[tb], " REG_STR(INSIDER_ORDER_ROW) "\n"        \
+    "s_load_dword %[p1], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x40\n"   \
+    "s_load_dword %[p2], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x80\n"   \
+    "s_add_u32 vcc_lo, s64, s98\n"                 \
+    "s_setpc_b64 vcc\n.p2align 12\n"              \
+    "Lc%=:\n"
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int WHO>
+__device__ __forceinline__ void reg_sweep(RegState<2> &S, const double (&G)[2][32], const uint32_t *tb)
+{
+    double dn;
+    int sk, p1, p2;
+    const uint64_t lm = 0x0001000100010001ull;
+    asm volatile(REGO_PROLOGUE REG_LIST_LO(REGO_LO) REG_HB_32(REGO_HI) REG_EPILOGUE(32)
+                 : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), [dn] "=&v"(dn), [sk] "=&s"(sk),
+                   [p1] "=&s"(p1), [p2] "=&s"(p2)
+                 : REG_LIST_LO(REG_GA) REG_HI_32(REG_GA) REG_LIST_LO(REG_GB) REG_HI_32(REG_GB)[i0] "v"(S.tau[0]), [i1] "v"(S.tau[1]),
+                   [tb] "s"(tb), [lm] "s"(lm)
+                 : "vcc", "scc", "memory", REG_S64_97, "s98", "s99");
+}
+#else
+template <int WHO>
+__device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][32], const uint32_t *) {}
+#endif
 
+#define REG_KM 16
+#define REG_PBN 64
+template <int WHO>
 __device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][16], const uint32_t *tb)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     double dn;
-    int sk, p1, p2;
+    int sk, p1, p2, p3;
     const uint64_t lm = 0x0001000100010001ull;
-    asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16)
-                 : [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
-                   [p2] "=&s"(p2)
-                 : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), [tb] "s"(tb), [lm] "s"(lm)
-                 : REG_CLOBBERS);
+    if constexpr (WHO == 0)
+        asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16) REG_PAIRS_OPEN REG_LIST_LO(REGP1_ROW_LO) REG_PAIRS_CLOSE
+                     : [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
+                       [p2] "=&s"(p2), [p3] "=&s"(p3)
+                     : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)
+                     : REG_CLOBBERS);
+    else
+        asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16)
+                     : [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
+                       [p2] "=&s"(p2), [p3] "=&s"(p3)
+                     : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)
+                     : REG_CLOBBERS);
 #endif
+}
+#undef REG_KM
+#undef REG_PBN
+
+// Address of the pair blocks of the KMAX instantiation of the column-update kernel (their own section: a pc-relative relocation)
+template <int KMAX>
+__device__ __forceinline__ uint64_t reg_pair_base()
+{
+    uint32_t lo = 0, hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_getpc_b64 s[98:99]\n"
+                 "s_add_u32 s98, s98, insider_cdpair_%c[km]@rel32@lo+4\n"
+                 "s_addc_u32 s99, s99, insider_cdpair_%c[km]@rel32@hi+12\n"
+                 "s_mov_b32 %[lo], s98\n"
+                 "s_mov_b32 %[hi], s99\n"
+                 : [lo] "=s"(lo), [hi] "=s"(hi)
+                 : [km] "i"(KMAX)
+                 : "s98", "s99", "scc");
+#endif
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Address of the table of code blocks of THIS kernel's sweep (the named label of REG_PROLOGUE): k_order_table adds the block
+// offsets to it, so the kernel that will run the sweeps is launched once with a null gene set to publish it (ColArgs::code_base)
+template <int KMAX, int WHO>
+__device__ __forceinline__ uint64_t reg_code_base()
+{
+    uint32_t lo = 0, hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_getpc_b64 s[98:99]\n"
+                 "Lq%=:\n"
+                 "s_add_u32 s98, s98, insider_cdtab_%c[km]_%c[who]-Lq%=\n"
+                 "s_addc_u32 s99, s99, 0\n"
+                 "s_mov_b32 %[lo], s98\n"
+                 "s_mov_b32 %[hi], s99\n"
+                 : [lo] "=s"(lo), [hi] "=s"(hi)
+                 : [km] "i"(KMAX), [who] "i"(WHO)
+                 : "s98", "s99", "scc");
+#endif
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // ---- 32 < K <= 48: three coordinate slots, the third slot's Gram columns in LDS (round 4) ---------------------------------
@@ -193,7 +427,7 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
 #define REG3_TAIL(KK, IT)                                                                            \
     REG_FMAC("h0", "ga" #KK, IT)                                                                     \
     REG_FMAC("h1", "gb" #KK, IT) "s_waitcnt lgkmcnt(0)\n"                                            \
-    "v_fmac_f64_dpp %[h2], %[dn], %[gc] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n" REG_JUMP
+    "v_fmac_f64_dpp %[h2], %[dn], %[gc] row_newbcast:" #IT " row_mask:0xf bank_mask:0xf\n" "s_setpc_b64 vcc\n"
 #define REG3_BLOCK_LO(KK) REG3_HEAD(KK, "h0", "b0", "i0", KK) REG3_TAIL(KK, KK)
 #define REG3_BLOCK_MID(KK, IT) REG3_HEAD(KK, "h1", "b1", "i1", IT) REG3_TAIL(KK, IT)
 #define REG3_BLOCK_TOP(KK, IT) REG3_HEAD(KK, "h2", "b2", "i2", IT) REG3_TAIL(KK, IT)
@@ -208,14 +442,14 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
     "s_addc_u32 s99, s99, 0\n"                     \
     "s_mov_b32 vcc_hi, s99\n"                      \
     "s_waitcnt lgkmcnt(0)\n"                       \
-    "s_load_dword %[sk], %[tb], 0x140\n"           /* the next row's list: four lines from byte 124 on */ \
-    "s_load_dword %[p1], %[tb], 0x144\n"           \
-    "s_load_dword %[p2], %[tb], 0x184\n"           \
-    "s_load_dword %[p3], %[tb], 0x1c4\n"           \
+    "s_load_dword %[sk], %[tb], " REG_STR(INSIDER_ORDER_ROW) "\n"        /* the next row's list: four lines from byte 124 on */ \
+    "s_load_dword %[p1], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x4\n"    \
+    "s_load_dword %[p2], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x44\n"   \
+    "s_load_dword %[p3], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x84\n"   \
     "s_add_u32 vcc_lo, s48, s98\n"                 \
     "s_setpc_b64 vcc\n.p2align 12\n"              \
     "Lc%=:\n"
-#define REG3_CLOBBERS REG_CLOBBERS, "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
+#define REG3_CLOBBERS "vcc", "scc", "memory", REG_S48_63 REG_S64_97, "s98", "s99"
 #define REG_T1_36(F) F(32) F(33) F(34) F(35)
 #define REG_T1_40(F) REG_T1_36(F) F(36) F(37) F(38) F(39)
 #define REG_T1_44(F) REG_T1_40(F) F(40) F(41) F(42) F(43)
@@ -227,6 +461,7 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
 // la: LDS byte address of this lane's cell in row 0 of the panel
 #if defined(__HIP_DEVICE_COMPILE__)
 #define REG_DEFINE_SWEEP3(KMAX)                                                                                          \
+    template <int WHO>                                                                                                   \
     __device__ __forceinline__ void reg_sweep(RegState<3> &S, const double (&G)[2][KMAX], const uint32_t *tb, uint32_t la) \
     {                                                                                                                    \
         double dn, gc;                                                                                                   \
@@ -244,6 +479,7 @@ constexpr int reg3_ps(int KMAX) { return 4 * reg3_w(KMAX) + 1; }            // p
     }
 #else
 #define REG_DEFINE_SWEEP3(KMAX) \
+    template <int WHO>          \
     __device__ __forceinline__ void reg_sweep(RegState<3> &, const double (&)[2][KMAX], const uint32_t *, uint32_t) {}
 #endif
 #define REG3_PS_STR "136"
@@ -260,6 +496,8 @@ REG_DEFINE_SWEEP3(48)
 #undef REG3_PS_STR
 static_assert(reg3_ps(36) * 8 == 136 && reg3_ps(40) * 8 == 264 && reg3_ps(44) * 8 == 392 && reg3_ps(48) * 8 == 520, "REG3_PS_STR");
 
+// does the instantiation take its successor list as absolute address pairs (else: 32-bit offsets)?
+__host__ __device__ constexpr bool reg_pairs(int KMAX) { return KMAX <= 30; }
 // waves per SIMD the register budget of an instantiation is sized for (512 VGPRs per SIMD lane)
 #ifndef INSIDER_REG_4WAVE_MAX
 #define INSIDER_REG_4WAVE_MAX 20   // largest KMAX built for 4 waves per SIMD (128 VGPRs)
@@ -399,7 +637,7 @@ __device__ __forceinline__ RegState<SLOTS> cd_reg_begin(int K, const double (&q)
 }
 
 // S: the start values of cd_reg_begin; beta / hs / is are outputs here
-template <int SLOTS, int KMAX>
+template <int SLOTS, int KMAX, int WHO>
 __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[reg_rs(SLOTS)][KMAX], int K, double (&beta)[SLOTS],
                                       bool gene_ok, const CdParams &P, int lane, double *stash, bool resume,
                                       double (&hs)[SLOTS], double (&is)[SLOTS], bool &unfinished, int &key, bool &capped,
@@ -458,8 +696,8 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[reg_r
     const uint32_t *tb = tb0 + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * (ORDER_ROW / 4);
     while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
         // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
-        if constexpr (SLOTS == 3) reg_sweep(S, G, tb, pla);
-        else reg_sweep(S, G, tb);
+        if constexpr (SLOTS == 3) reg_sweep<WHO>(S, G, tb, pla);
+        else reg_sweep<WHO>(S, G, tb);
         ++sweep;
         tb = (sweep & (int)(INSIDER_PERM_PERIOD - 1)) ? tb + ORDER_ROW / 4 : tb0;
         // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
@@ -595,6 +833,15 @@ template <int SLOTS, int KMAX, bool SOLVE>
 __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
 {
     const int lane = threadIdx.x;
+    if constexpr (SOLVE && reg_pairs(KMAX)) {
+        if (a.code_base) {   // probe launch (wave-uniform): where this kernel's table of code blocks lies, for k_order_table
+            if (blockIdx.x == 0 && lane == 0) {
+                a.code_base[0] = reg_code_base<KMAX, 0>();
+                a.code_base[1] = reg_pair_base<KMAX>();
+            }
+            return;
+        }
+    }
     const int K = a.K, KP = a.KP;
     const bool resume = a.resume != 0;
     const double gs = a.cd.inv_two_la;
@@ -655,7 +902,7 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
         }
         if constexpr (SLOTS == 3) wave_sync();
         if constexpr (SOLVE)                                                              // :228,246
-            sweeps = cd_reg<SLOTS, KMAX>(S, G, K, beta, w.gene, a.cd, lane, stash, resume, hs, is, unfinished, key, capped, panel);
+            sweeps = cd_reg<SLOTS, KMAX, 0>(S, G, K, beta, w.gene, a.cd, lane, stash, resume, hs, is, unfinished, key, capped, panel);
     }
     // ---- results: everything that addresses the gene is formed again, from a laundered lane id ------------------------
     int lane_c = lane;
@@ -744,9 +991,16 @@ __global__ void __launch_bounds__(64, reg_waves(KMAX)) k_cd_cols_reg(ColArgs a)
 template <int SLOTS, int KMAX>
 __global__ void __launch_bounds__(64, KMAX >= 30 ? 2 : reg_waves(KMAX))
 k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, const double *__restrict__ wstart, int K,
-               int64_t nprob, CdParams cd, double *__restrict__ beta_out, int *__restrict__ sweeps_out)
+               int64_t nprob, CdParams cd, double *__restrict__ beta_out, int *__restrict__ sweeps_out,
+               unsigned long long *__restrict__ code_base = nullptr)
 {
     const int lane = threadIdx.x;
+    if constexpr (reg_pairs(KMAX)) {
+        if (code_base) {   // probe launch: see k_cd_cols_reg
+            if (blockIdx.x == 0 && lane == 0) *code_base = reg_code_base<KMAX, 1>();
+            return;
+        }
+    }
     __shared__ double stash[reg_stash(SLOTS)];
     double *const panel = RegPanel<SLOTS, KMAX>::get();
     double G[reg_rs(SLOTS)][KMAX], beta[SLOTS];
@@ -797,7 +1051,7 @@ k_cd_batch_reg(const double *__restrict__ XtX, const double *__restrict__ Xty, c
         if constexpr (SLOTS == 3) wave_sync();
         bool unfinished, capped;
         int key;
-        sw = cd_reg<SLOTS, KMAX>(S, G, K, beta, prob, cd, lane, stash, false, hs, is, unfinished, key, capped, panel);
+        sw = cd_reg<SLOTS, KMAX, 1>(S, G, K, beta, prob, cd, lane, stash, false, hs, is, unfinished, key, capped, panel);
     }
     int lane_c = lane;
 #if defined(__HIP_DEVICE_COMPILE__)

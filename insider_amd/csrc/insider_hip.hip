@@ -182,6 +182,11 @@ struct insider_hip_handle {
     int *sweeps = nullptr, *failflag = nullptr;
     int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sched_bucket)
     unsigned long long *sweep_total = nullptr;
+    // where the register-resident sweep kernel of the current K keeps its table of code blocks (K <= 32; 0 = not asked yet): the
+    // order table holds absolute block addresses (insider_cd_reg.hpp), published by a probe launch of that kernel
+    unsigned long long cd_code_base = 0, cd_pair_base = 0;
+    unsigned long long *code_base_dev = nullptr;   // where the probe launch stores them (workspace)
+    int cd_pairs = 1;                  // option "cd_pairs": route the sweeps through the kernel's blocks of two coordinate steps (default)
     uint8_t *order = nullptr;          // the sweep-order table the next column solve reads: one of order_buf
     uint8_t *order_buf[2] = {nullptr, nullptr};   // two tables: the next outer iteration's is built while the current solve runs
     hipEvent_t ev_tab = nullptr;
@@ -252,7 +257,7 @@ std::vector<void **> workspace_slots(insider_hip_handle *h)
     add(h->b1); add(h->loss_buf); add(h->stage); add(h->wg_part); add(h->wg_pair); add(h->sweeps); add(h->sweep_key); add(h->failflag);
     add(h->sweep_total); add(h->order_buf[0]); add(h->order_buf[1]); add(h->gene_perm); add(h->sched_cnt[0]); add(h->sched_cnt[1]);
     add(h->sched_rank); add(h->sched_bkt); add(h->sched_long); add(h->cd_hsave); add(h->cd_isave); add(h->cd_pass_slot);
-    add(h->cd_pass_perm[0]); add(h->cd_pass_perm[1]); add(h->cd_pass_cnt);
+    add(h->cd_pass_perm[0]); add(h->cd_pass_perm[1]); add(h->cd_pass_cnt); add(h->code_base_dev);
     for (int e = 0; e < insider_hip_handle::EARLY; ++e) add(h->perm_early[e]);
     return v;
 }
@@ -263,6 +268,7 @@ void forget_workspace(insider_hip_handle *h)
     for (void **slot : workspace_slots(h)) *slot = nullptr;
     h->order = nullptr;
     h->order_rows = 0;
+    h->cd_code_base = h->cd_pair_base = 0;
     h->sched_long_valid = false;
     for (int e = 0; e < insider_hip_handle::EARLY; ++e) h->have_early[e] = false;
     h->have_perm = false;
@@ -403,6 +409,7 @@ int ensure_workspace(insider_hip_handle *h, int K)
     if ((rc = dmalloc(&h->cd_pass_perm[0], (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->cd_pass_perm[1], (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->cd_pass_cnt, (size_t)CD_BUCKETS + 2))) return rc;
+    if ((rc = dmalloc(&h->code_base_dev, 2))) return rc;
     for (int e = 0; e < insider_hip_handle::EARLY; ++e)
         if ((rc = dmalloc(&h->perm_early[e], (size_t)h->p))) return rc;
     HIPCHECK(hipMemsetAsync(h->sched_cnt[0], 0, SCHED_BUCKETS * sizeof(int), h->stream));
@@ -580,9 +587,32 @@ struct Timer {   // HIP-event pair around one launch on the library's stream (op
 // 32 < K <= 48 with an l1 term: the register-resident kernel with its third slot's matrix columns in LDS (insider_cd_reg.hpp)
 static bool reg3_path(int K, double la, int variant) { return K > 32 && K <= 48 && la > 0.0 && variant == 0; }
 
+// the address of the table of code blocks of k_cd_cols_reg<., KMAX(K), true> on this device (K <= 32): one probe launch per workspace
+int ensure_code_base(insider_hip_handle *h, int K)
+{
+    if (!reg_pairs(reg_kmax(K)) || h->cd_code_base) return INSIDER_OK;
+    unsigned long long *d = h->code_base_dev;
+    HIPCHECK(hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), h->stream));
+    ColArgs a{};
+    a.p = 0;
+    a.K = K;
+    a.KP = h->KP;
+    a.code_base = d;
+    REG_DISPATCH(K, hipLaunchKernelGGL((k_cd_cols_reg<SL_, KM_, true>), dim3(1), dim3(64), 0, h->stream, a));
+    KCHECK();
+    unsigned long long v[2] = {0, 0};
+    HIPCHECK(hipMemcpyAsync(v, d, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (!v[0] || !v[1]) return fail(INSIDER_ERR_HIP, "the sweep kernel did not publish the addresses of its code blocks");
+    h->cd_code_base = v[0];
+    h->cd_pair_base = v[1];
+    return INSIDER_OK;
+}
+
 int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int K, int max_sweeps, int order_mode, double la,
                        hipStream_t stream = nullptr, int slot = 0)
 {
+    if (int rb = ensure_code_base(h, K)) return rb;
     if (!stream) stream = h->stream;
     // one period of the order sequence at most (include/insider_perm.h): the table does not grow with max_sweeps
     const int rows = std::min<int64_t>(max_sweeps, INSIDER_PERM_PERIOD);
@@ -597,7 +627,8 @@ int ensure_order_table(insider_hip_handle *h, uint64_t seed, uint32_t iter, int 
     }
     // rows for K > 32 carry 64 row offsets (row16 kernel) unless the solve takes the register-resident kernel's successor list
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)(rows + 1) * 64, 256)), dim3(256), 0, stream, seed, iter, K, rows,
-                       order_mode, K * 8, reg_kmax(K), (K > 32 && !reg3_path(K, la, h->cd_variant)) ? 1 : 0, h->order_buf[slot]);
+                       order_mode, K * 8, reg_kmax(K), (K > 32 && !reg3_path(K, la, h->cd_variant)) ? 1 : 0, h->cd_code_base,
+                       h->cd_pairs ? h->cd_pair_base : 0ull, h->order_buf[slot]);
     KCHECK();
     if (!h->order) h->order = h->order_buf[slot];
     return INSIDER_OK;
@@ -2132,6 +2163,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
     else if (s == "list_fine") h->list_fine = (int)value;       // 1 (default) = per-entry statistics on v_mfma_f64_4x4x4 for 16 <= K <= 31, 0 = on 16x16x4
+    else if (s == "cd_pairs") h->cd_pairs = (int)value;           // 1 (default) = sweeps routed through the blocks of two coordinate steps (K <= 30; same iterates), 0 = one step per block
     else if (s == "cd_split") h->cd_split = (int)value;           // 2 = steady-state column steps run split (long genes first, on their own stream); 0 (default) = never (measured: no gain, see use_split)
     else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)
     else if (s == "cd_variant") h->cd_variant = (int)value;   // 0 = register-resident (4 genes per wave; K <= 32, and 32 < K <= 48 with the third slot's columns in LDS), 1 = group kernel, 2 = row16 (LDS, K <= 48)
@@ -2449,8 +2481,19 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
     const char *var = std::getenv("INSIDER_CD_VARIANT");
     const int variant = var ? std::atoi(var) : 0;
     const bool reg3 = reg3_path(K, lambda * alpha, variant);
+    unsigned long long code_base = 0;
+    if (reg_pairs(reg_kmax(K)) && variant == 0 && lambda * alpha > 0.0) {   // the register-resident batch kernel will run: where are its code blocks?
+        unsigned long long *dcb = nullptr;
+        if ((rc = bufs.alloc(&dcb, 1))) return rc;
+        HIPCHECK(hipMemset(dcb, 0, sizeof(unsigned long long)));
+        CdParams none{};
+        REG_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(1), dim3(64), 0, 0, dG, dq, dw, K, (int64_t)0, none, db, ds, dcb));
+        KCHECK();
+        HIPCHECK(hipMemcpy(&code_base, dcb, sizeof(code_base), hipMemcpyDeviceToHost));
+        if (!code_base) return fail(INSIDER_ERR_HIP, "the sweep kernel did not publish the address of its code blocks");
+    }
     hipLaunchKernelGGL(k_order_table, dim3(cdiv((int64_t)(rows + 1) * 64, 256)), dim3(256), 0, 0, seed, iter, K, rows, order_mode, K * 8,
-                       reg_kmax(K), (K > 32 && !reg3) ? 1 : 0, dord);
+                       reg_kmax(K), (K > 32 && !reg3) ? 1 : 0, code_base, 0ull, dord);
     KCHECK();
     CdParams cd;
     cd.lambda = lambda;
@@ -2476,12 +2519,12 @@ static int strong_cd_device(DevBufs &bufs, const double *dG, const double *dq, c
         hipLaunchKernelGGL((k_cd_batch_r16<2>), dim3(cdiv(nprob, 4)), dim3(64), r16_bytes, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32 && cd.la > 0.0) {   // (the register-resident solver's state is scaled by 1 / (2 lambda alpha))
         REG_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0, dG, dq, dw, K,
-                                           nprob, cd, db, ds));
+                                           nprob, cd, db, ds, (unsigned long long *)nullptr));
     } else if (K <= 16) hipLaunchKernelGGL((k_cd_batch<16, 4>), dim3(cdiv(nprob, 16)), dim3(256), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (K <= 32) hipLaunchKernelGGL((k_cd_batch<32, 2>), dim3(cdiv(nprob, 4)), dim3(128), 0, 0, dG, dq, dw, K, nprob, cd, db, ds);
     else if (reg3) {   // 32 < K <= 48: register-resident with the third slot's matrix columns in LDS
         REG3_DISPATCH(K, hipLaunchKernelGGL((k_cd_batch_reg<SL_, KM_>), dim3(cdiv(nprob, 4)), dim3(64), 0, 0, dG, dq, dw, K,
-                                            nprob, cd, db, ds));
+                                            nprob, cd, db, ds, (unsigned long long *)nullptr));
     }
     else if (K <= 48 && variant != 1) {   // lambda alpha = 0 or INSIDER_CD_VARIANT=2: the LDS-resident row16 solver (=1: one problem per wavefront)
         if (int rl = r16_wide_lds(r16_bytes)) return rl;

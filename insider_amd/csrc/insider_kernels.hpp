@@ -31,7 +31,8 @@ constexpr int WAVE = 64;
 constexpr int CHUNK = 128;      // elements per streaming step (2 per lane); line pitches are multiples of it
 
 constexpr int LEVEL_CHUNK = 4;   // member samples per wave of k_level_partial (row update, stage 1)
-constexpr int ORDER_ROW = 320;   // bytes per sweep in the coordinate-order table (see k_order_table)
+#define INSIDER_ORDER_ROW 448    // (a macro as well: the sweep assembly of insider_cd_reg.hpp spells it in its load offsets)
+constexpr int ORDER_ROW = INSIDER_ORDER_ROW;   // bytes per sweep in the coordinate-order table (see k_order_table)
 
 constexpr int CODE_TRAIN = 1;   // bit 0 of a mask code: entry is in the train set
 constexpr int CODE_TEST = 2;    // bit 1: entry is in the test set (neither bit: NA)
@@ -361,21 +362,29 @@ __device__ __forceinline__ int cd_sweeps(const double *Goff, int *s_ord, int K, 
 }
 
 // bytes between the code blocks of consecutive coordinates in the register-resident sweep (insider_cd_reg.hpp).  A block is
-// 60 bytes long; 64-byte spacing (one instruction-cache line per block) measured the same as 96 (c3: 311 against 311-315
-// iterations/s), like the 128 ... 256-byte spacings of round 2: the cost of the computed jump is not the number of lines fetched
+// 56 bytes long: one 64-byte instruction-cache line per block (64, 96 and 128 ... 256-byte spacings measured the same in rounds
+// 2 - 4: the cost of the computed jump is not the number of lines fetched)
 #ifndef INSIDER_REG_BLOCK
-#define INSIDER_REG_BLOCK 96
+#define INSIDER_REG_BLOCK 64
 #endif
 #define INSIDER_REG3_BLOCK 80   // ... in its three-slot form (32 < K <= 48): the blocks are exactly this long and packed, 49 of them stay below 4 KiB
 
 // Order table, one row of ORDER_ROW bytes per sweep s < nsweeps: bytes [0, 64): the K coordinates in ascending key
 // order (order_mode 0) or 0..K-1 (cyclic); bytes [64, 128): 32 uint16 = coordinate * pitch_bytes (row offsets for
-// the row16 kernel; K > 32: 64 of them, bytes [64, 192)); bytes [128, 320), K <= 32: 48 uint32, the code-block offsets of the register-resident kernel
-// (insider_cd_reg.hpp) as a successor list: dword 0 = INSIDER_REG_BLOCK * (first coordinate of the sweep), dword 1 + k = INSIDER_REG_BLOCK * (the
-// coordinate visited after k), exit_block for the last one and for k >= K; 32 < K <= 48 on that kernel (wide_rows = 0): the same
-// list from byte 124 on (30 row offsets).  One thread per (sweep, coordinate): rank by counting.
+// the row16 kernel; K > 32: 64 of them, bytes [64, 192)).  Bytes [128, 128 + 8 (1 + KMAX)), K <= 30: the successor list of the
+// register-resident kernel (insider_cd_reg.hpp) as ABSOLUTE code addresses, 64 bits each: entry 0 = the block of the sweep's first
+// coordinate, entry 1 + k = the block visited after coordinate k, the exit block (index exit_block = KMAX) after the last one
+// and for k >= K; a block's address is code_base + INSIDER_REG_BLOCK * its index, code_base = where the kernel that will run
+// the sweeps keeps its table of blocks (published by a probe launch, reg_code_base).  K = 31, 32: 32-bit block OFFSETS from byte
+// 128 on (33 pairs do not fit beside the kernel's own scalars).  32 < K <= 48 on that kernel (wide_rows = 0): 32-bit offsets
+// (INSIDER_REG3_BLOCK apart) from byte 124 on, 1 + K of them, and 30 row offsets.  One thread per (sweep, coordinate): rank by counting.
+// pair_base != 0 (K <= 30): the sweep is cut greedily, from its first position on, into PAIRS of consecutive coordinates of one
+// coordinate slot and single coordinates, and routed through the kernel's blocks of two steps (insider_cd_reg.hpp: pair (a, b) of
+// slot 0 at pair_base + 128 (16 a + b), of slot 1 at pair_base + 128 (256 + W (a - 16) + (b - 16)), W = exit_block - 16); entry
+// 1 + l is then the block after the block that ENDS with coordinate l.  Same steps in the same order: the iterates do not change.
 __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t iter, int K, int nsweeps, int order_mode,
-                                                     int pitch_bytes, int exit_block, int wide_rows, uint8_t *__restrict__ order)
+                                                     int pitch_bytes, int exit_block, int wide_rows, unsigned long long code_base,
+                                                     unsigned long long pair_base, uint8_t *__restrict__ order)
 {
     __shared__ uint8_t by_rank[4][64];
     __shared__ uint32_t keys[4][64];
@@ -395,22 +404,61 @@ __global__ void __launch_bounds__(256) k_order_table(uint64_t seed, uint32_t ite
     if (l < K) by_rank[w][rank] = (uint8_t)l;
     __syncthreads();
     if (!live) return;
-    uint32_t *blk = reinterpret_cast<uint32_t *>(row + 128);
     // wide rows (K > 32 on the row16 kernel with three or four slots): 64 row offsets in bytes [64, 192) and no successor list,
     // which shares those bytes; 32 < K <= 48 on the register-resident kernel: the list (1 + K <= 49 dwords from byte 124), 30 row offsets
     const bool wide = wide_rows != 0;
-    // narrow rows for K > 32 (three-slot register kernel, K <= 48) hold the list one dword earlier — first block at byte 124,
+    if (K <= 30) {
+        unsigned long long *pr = reinterpret_cast<unsigned long long *>(row + 128);
+        const unsigned long long bb = INSIDER_REG_BLOCK, exit_addr = code_base + bb * (unsigned)exit_block;
+        if (l >= K) {
+            row[l] = 0;
+            if (l < 32) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
+            if (l < exit_block) pr[1 + l] = exit_addr;
+            return;
+        }
+        row[rank] = (uint8_t)l;
+        if (rank < 32) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
+        if (pair_base) {
+            const uint8_t *ord = by_rank[w];
+            const int W = exit_block - 16;
+            auto pairs = [&](int a, int b) { return (a >> 4) == (b >> 4); };
+            auto block_at = [&](int pos) -> unsigned long long {
+                if (pos >= K) return exit_addr;
+                const int a = ord[pos];
+                if (pos + 1 < K && pairs(a, ord[pos + 1])) {
+                    const int b = ord[pos + 1];
+                    return pair_base + 128ull * (unsigned)(a < 16 ? a * 16 + b : 256 + (a - 16) * W + (b - 16));
+                }
+                return code_base + bb * (unsigned)a;
+            };
+            int pos = 0, len = 1;
+            for (;;) {      // every lane walks the cut up to its own coordinate
+                len = (pos + 1 < K && pairs(ord[pos], ord[pos + 1])) ? 2 : 1;
+                if (rank < pos + len) break;
+                pos += len;
+            }
+            pr[1 + l] = block_at(pos + len);          // (read by a block only when l is its last coordinate)
+            if (rank == 0) pr[0] = block_at(0);
+            return;
+        }
+        pr[1 + l] = rank + 1 < K ? code_base + bb * by_rank[w][rank + 1] : exit_addr;
+        if (rank == 0) pr[0] = code_base + bb * (unsigned)l;
+        return;
+    }
+    uint32_t *blk = reinterpret_cast<uint32_t *>(row + 128);
+    // K = 31, 32 (KMAX = 32: offsets, INSIDER_REG_BLOCK apart): dword 0 at byte 128 = first block, dword 1 + k = the block after k.
+    // Narrow rows for K > 32 (three-slot register kernel, K <= 48) hold the list one dword earlier — first block at byte 124,
     // successor of coordinate k at 128 + 4 k — so that 1 + 48 dwords fit the row; the kernel loads from byte 124 there
-    const int shift = K > 32 ? 1 : 0;
+    const int shift = K > 32 ? 1 : 0, nrow = shift ? 30 : 32;
     const uint32_t bb = K > 32 ? (uint32_t)INSIDER_REG3_BLOCK : (uint32_t)INSIDER_REG_BLOCK;   // bytes per code block
     if (l >= K) {
         row[l] = 0;
-        if (l < (shift ? 30 : 32) || wide) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
+        if (l < nrow || wide) reinterpret_cast<uint16_t *>(row + 64)[l] = 0;
         if (l < 47 + shift && !wide) blk[1 + l - shift] = (uint32_t)exit_block * bb;
         return;
     }
     row[rank] = (uint8_t)l;
-    if (rank < (shift ? 30 : 32) || wide) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
+    if (rank < nrow || wide) reinterpret_cast<uint16_t *>(row + 64)[rank] = (uint16_t)(l * pitch_bytes);
     if (wide) return;
     if (l < 47 + shift) blk[1 + l - shift] = rank + 1 < K ? (uint32_t)by_rank[w][rank + 1] * bb : (uint32_t)exit_block * bb;
     if (rank == 0) blk[0 - shift] = (uint32_t)l * bb;
@@ -881,6 +929,9 @@ struct ColArgs {
     int *sched_key, *sched_cnt, *sched_rank;
     uint16_t *sched_bkt;
     int sched_reset;
+    unsigned long long *code_base = nullptr;   // probe launch of the register-resident kernel (K <= 30): the addresses of its table of
+                                               // code blocks [0] and of its blocks of two steps [1] are stored here and nothing
+                                               // else is done (insider_cd_reg.hpp)
 };
 
 constexpr int CD_BUCKETS = 192;                  // 8 per octave of the estimate (1 .. 2^20 sweeps), longest first

@@ -879,8 +879,8 @@ def test_operators_reject_bad_arguments():
     ds.close()
 
 
-@pytest.mark.parametrize("K", [7, 30])
-def test_device_order_table_matches_golden(K):
+@pytest.mark.parametrize("K,pairs", [(7, 0), (30, 0), (30, 1), (23, 1), (7, 1)])
+def test_device_order_table_matches_golden(K, pairs):
     """The sweep-order table the device kernels read (k_order_table) against the committed golden orders of
     include/insider_perm.h (tests/golden/perm_golden.json): oracle and product share that header, so only fixed bytes can
     catch an edit of it.  Also decodes the successor list the register-resident sweep kernel jumps through."""
@@ -890,26 +890,87 @@ def test_device_order_table_matches_golden(K):
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "perm_golden.json")))
     w = workloads.small(K=K, n=60, p=20, seed=3)
     ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test)
+    ds.set_option("cd_pairs", pairs)
     checked = 0
+    have = {g["K"] for g in gold}
     for seed, it in sorted({(g["seed"], g["iter"]) for g in gold}):
         A, Cm = _cp(w)
         ds.optimize_col(A, Cm, lambda_=w.lam, alpha=0.4, tuning=1, tol=1e-3, seed=seed, it=it)
         rows = 16384 + 1
-        tab = np.zeros(rows * 320, dtype=np.uint8)
+        ROW = 448                                       # ORDER_ROW: bytes per sweep (insider_kernels.hpp)
+        tab = np.zeros(rows * ROW, dtype=np.uint8)
         _lib.check(_lib.load().insider_hip_get_array(ds._h, b"order_table", tab.ctypes.data_as(C.c_void_p), tab.nbytes))
-        tab = tab.reshape(rows, 320)
+        tab = tab.reshape(rows, ROW)
         for g in gold:
-            if (g["seed"], g["iter"], g["K"]) != (seed, it, K):
+            if (g["seed"], g["iter"]) != (seed, it) or g["K"] != (K if K in have else 30):
                 continue
             row = tab[g["sweep"] % 16384]
+            if K not in have:      # no golden orders for this K: the row's own order bytes are the walk's reference
+                g = dict(g, order=row[:K].tolist())
+                assert sorted(g["order"]) == list(range(K))
             assert row[:K].tolist() == g["order"], g
-            # successor list (bytes 128..): dword 0 = first block, dword 1 + k = block after coordinate k, exit block last
-            blk = row[128:128 + 4 * 48].view(np.uint32)
-            unit = 96                                   # INSIDER_REG_BLOCK: bytes between the code blocks of two coordinates
-            walk, cur = [], int(blk[0]) // unit
+            if K <= 30:
+                # successor list (bytes 128..): 64-bit ABSOLUTE code addresses — entry 0 = first block, entry 1 + k = block after
+                # coordinate k, the exit block (index KMAX) last; a block's address = table base + 64 * its index, and every sweep
+                # visits coordinate 0, whose block IS the base
+                kmax = 16 if K <= 16 else (K + 1) & ~1
+                pr = row[128:128 + 8 * (1 + kmax)].view(np.uint64)
+                if pairs:
+                    # routed through the blocks of TWO steps (option cd_pairs): entry 1 + l = the block after the block that ENDS
+                    # with coordinate l; pair (a, b) of slot 0 at pair_base + 128 (16 a + b), of slot 1 at pair_base + 128 (256 +
+                    # W (a - 16) + (b - 16)), W = kmax - 16; single blocks and the exit block in the table of single steps.  The
+                    # exit block is the LARGEST address of the single table (the entries of k >= K and of the last block hold it)
+                    exit_addr = int(pr[1 + g["order"][-1]])
+                    base = exit_addr - 64 * kmax
+                    W, walk, cur, jumps = kmax - 16, [], int(pr[0]), 0
+                    pbase = 0
+                                    def decode(addr, pb):
+                        idx, rem = divmod(addr - pb, 128)
+                        if rem or idx < 0:
+                            return None
+                        if idx < 256:
+                            return [idx // 16, idx % 16]
+                        idx -= 256
+                        return [16 + idx // W, 16 + idx % W] if W > 0 and idx < W * W else None
+                    greedy, t = 0, 0
+                    while t < K:
+                        t += 2 if (t + 1 < K and g["order"][t] // 16 == g["order"][t + 1] // 16) else 1
+                        greedy += 1
+                    # the pair base: the address of the first pair of the greedy cut fixes it
+                    t = 0
+                    while t < K and not (t + 1 < K and g["order"][t] // 16 == g["order"][t + 1] // 16):
+                        t += 1
+                    if t < K:
+                        a, b = g["order"][t], g["order"][t + 1]
+                        first_pair_addr = int(pr[0]) if t == 0 else int(pr[1 + g["order"][t - 1]])
+                        pbase = first_pair_addr - 128 * (16 * a + b if a < 16 else 256 + W * (a - 16) + (b - 16))
+                    while cur != exit_addr:
+                        if base <= cur < exit_addr:
+                            assert (cur - base) % 64 == 0
+                            walk.append((cur - base) // 64)
+                        else:
+                            ab = decode(cur, pbase)
+                            assert ab is not None and ab[0] // 16 == ab[1] // 16 and ab[0] != ab[1], (cur, pbase)
+                            walk += ab
+                        jumps += 1
+                        assert len(walk) <= K
+                        cur = int(pr[1 + walk[-1]])
+                    assert walk == g["order"] and jumps == greedy, (walk, g, jumps, greedy)
+                    checked += 1
+                    continue
+                base, unit = int(pr.min()), 64          # INSIDER_REG_BLOCK
+                assert base > 0 and base % 4 == 0
+                blk = [(int(v) - base) // unit for v in pr]
+                assert all((int(v) - base) % unit == 0 for v in pr) and max(blk) == kmax
+            elif K <= 32:
+                blk = [int(v) // 64 for v in row[128:128 + 4 * (1 + K)].view(np.uint32)]      # K = 31, 32: 32-bit block offsets
+            else:
+                # 32 < K <= 48: 32-bit block offsets from byte 124 on (INSIDER_REG3_BLOCK = 80 bytes apart)
+                blk = [int(v) // 80 for v in row[124:124 + 4 * (1 + K)].view(np.uint32)]
+            walk, cur = [], blk[0]
             while len(walk) < K:
                 walk.append(cur)
-                cur = int(blk[1 + cur]) // unit
+                cur = blk[1 + cur]
             assert walk == g["order"], (walk, g)
             checked += 1
         assert np.array_equal(tab[16384], tab[0])      # the look-ahead row = sweep 16384 = sweep 0 of the next period

@@ -160,13 +160,26 @@ def test_sweep_kernels_do_not_spill(tmp_path, lib):
         scratch = [t for _a, t, _r in ins if t.startswith(("scratch_", "buffer_load", "buffer_store"))]
         if kmax <= 30:
             assert not scratch, (head, scratch[:4])
-        # the sweep's prologue: its table loads end with the s_getpc_b64 that anchors the code-block table
-        sites = [i - (4 if kmax > 32 else 3) for i, (_, t, _r) in enumerate(ins) if t.startswith("s_getpc_b64 s[98:99]")]
+        # the sweep's prologue starts with the loads of the successor list: absolute address pairs into s[96 - 2 KMAX : 97] for
+        # KMAX <= 30 (round 5), 32-bit offsets into s[64:97] (KMAX = 32) / s[48:96] (three slots: four loads), followed there by
+        # the s_getpc_b64 that anchors the table of code blocks
+        pb = 96 - 2 * kmax
+        first = f"s_load_dwordx16 s[{pb}:{pb + 15}]" if kmax <= 30 else ("s_load_dwordx16 s[48:63]" if kmax > 32 else "s_load_dwordx16 s[64:79]")
+        sites = [i for i, (_, t, _r) in enumerate(ins) if t.startswith(first)]
         if "k_cd_cols_reg" in head and "ELb0E" in head:
-            assert not sites, head                 # the evaluation kernels have no sweep loop
+            assert not sites and not any(t.startswith("s_setpc_b64") for _a, t, _r in ins), head   # the evaluation kernels have no sweep loop
             continue
-        first = "s_load_dwordx16 s[48:63]" if kmax > 32 else "s_load_dwordx16 s[64:79]"   # (three slots: 49 list dwords, four loads)
-        assert len(sites) == 1 and ins[sites[0]][1].startswith(first), (head, len(sites))
+        assert len(sites) == 1, (head, len(sites))
+        if kmax > 30:
+            assert ins[sites[0] + (4 if kmax > 32 else 3)][1].startswith("s_getpc_b64 s[98:99]"), head
+        else:      # one computed jump per code block and one into the first block, each on its own register pair; no address add
+            jumps = [t for _a, t, _r in ins if t.startswith("s_setpc_b64 s[")]
+            assert len(set(jumps)) == kmax + 1, (head, len(set(jumps)))
+            # the column-update kernel also carries its blocks of two steps (a section of their own behind insider_cdpair_<KMAX>;
+            # the disassembly lists them under the kernel in front of that label): one jump per block, 16 x 16 + W x W of them
+            npair = 256 + (kmax - 16) ** 2 if "k_cd_cols_reg" in head else 0
+            assert len(jumps) in (kmax + 1, kmax + 1 + npair), (head, len(jumps))
+            assert not any(t.startswith("s_add_u32 vcc_lo") for _a, t, _r in ins), head
         a0 = ins[sites[0]][0]
         # the loop's back edge: the first branch after the sweep whose target lies at or shortly before the sweep's first load
         back = None

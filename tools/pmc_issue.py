@@ -114,10 +114,15 @@ ij = json.load(open(ipath)) if os.path.exists(ipath) else {}
 sha = _build.library_sha()
 if ij.get("source_sha") != sha:
     ij = {}
-try:
-    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "?"
-except Exception:
-    commit = "?"
+# the GPU box has no .git: the commit comes from the job that starts the passes (INSIDER_COMMIT, set here before gpurun)
+commit = os.environ.get("INSIDER_COMMIT", "").strip()
+if not commit:
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    except Exception:
+        commit = ""
+commit = commit or "not recorded (no .git on the GPU box; source_sha identifies the sources)"
+extra = os.environ.get("INSIDER_PMC_EXTRA", "").strip()
 
 
 def pick(pred):
@@ -133,9 +138,15 @@ def pick(pred):
             "salu_per_valu_inst": d.get("salu_per_valu_inst"), "active_lanes_per_valu": d.get("lanes"), "mfma_busy": d.get("mfma_busy")}
 
 
-ij.update({"source_sha": sha, "commit": commit,
-           "command": f"rocprofv3 --pmc <SQ_* pass> -- python3 bench.py --workload {wl} --steps 4 --warmup 0 --no-cpu-baseline (tools/pmc_issue.sh)"})
-ij[wl] = {"sweep_kernel": pick(lambda k: k.startswith("k_cd_cols") and "false" not in k),
+# every entry carries ITS OWN command and commit (round 4's file had one top-level command, the last workload's)
+base_wl = wl.split("_")[0]
+ij["source_sha"] = sha
+ij.pop("command", None)
+ij.pop("commit", None)
+ij[wl] = {"command": (f"rocprofv3 --pmc <SQ_* pass> -- python3 bench.py --workload {base_wl} --steps 4 --warmup 0 --no-cpu-baseline"
+                      + (" " + extra if extra else "") + " (three passes, tools/pmc_issue.sh)"),
+          "commit": commit,
+          "sweep_kernel": pick(lambda k: k.startswith("k_cd_cols") and "false" not in k),
           "statistics_kernel": pick(lambda k: k.startswith(("k_col_paircnt", "k_col_factored", "k_list_stats")))}
 json.dump(ij, open(ipath, "w"), indent=1)
 print("profiles/issue.json updated for", wl, "source_sha", sha)

@@ -22,5 +22,5 @@ for P in "$P1" "$P2" "$P3"; do
   echo "pass $i done"
 done
 cd $R
-INSIDER_ISSUE_JSON=$OUT/issue.json python3 tools/pmc_issue.py $LBL $OUT/${LBL}_pmc_issue $OUT/pmc_issue_${LBL}_1 $OUT/pmc_issue_${LBL}_2 $OUT/pmc_issue_${LBL}_3
+INSIDER_PMC_EXTRA="$EXTRA" INSIDER_ISSUE_JSON=$OUT/issue.json python3 tools/pmc_issue.py $LBL $OUT/${LBL}_pmc_issue $OUT/pmc_issue_${LBL}_1 $OUT/pmc_issue_${LBL}_2 $OUT/pmc_issue_${LBL}_3
 echo PMC_ISSUE_DONE

@@ -71,9 +71,15 @@ def main():
     tj = json.load(open(path)) if os.path.exists(path) else {}
     if tj.get("source_sha") != source_sha():
         tj = {}
-    tj.update({"source_sha": source_sha(), "commit": commit,
-               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --workload W --steps 4 --warmup 0 --no-cpu-baseline",
-               name: ent})
+    # every entry carries its own command and commit
+    ent["command"] = (f"rocprofv3 --pmc FETCH_SIZE -- / --pmc WRITE_SIZE -- python3 bench.py --workload {name.split('_')[0]} --steps 4 "
+                      f"--warmup 0 --no-cpu-baseline" + (" " + os.environ["INSIDER_PMC_EXTRA"] if os.environ.get("INSIDER_PMC_EXTRA") else "")
+                      + " (separate passes)")
+    ent["commit"] = os.environ.get("INSIDER_COMMIT", "").strip() or commit
+    tj["source_sha"] = source_sha()
+    tj.pop("command", None)
+    tj.pop("commit", None)
+    tj[name] = ent
     json.dump(tj, open(path, "w"), indent=1)
     print(json.dumps({k: v for k, v in ent.items() if k != "per_kernel"}))
 

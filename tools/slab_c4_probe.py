@@ -1,9 +1,14 @@
-"""Diagnostics (GPU): one rank's share of the strong-scaled c4 problem on ONE GPU: a gene slab of c4's first p/N genes, 11 outer
-iterations (bench.py's c4 command), against the whole problem's 16.5 ms per iteration: what strong scaling can reach before any
-exchange cost (the slab's own row factors differ from the full problem's, the timing is representative)."""
+"""Diagnostics (GPU): a gene slab of c4's first p/N genes as a problem of ITS OWN, 11 outer iterations (bench.py's c4 command),
+against the whole problem's time per iteration (profiles/single_gpu.json).  NOT the sharded run: the slab's row factors are
+estimated from its own genes, so its sweep counts are another problem's (round 4's 3.98 x "before any exchange cost" came from
+this).  What a rank of the N-GPU job really does — global row factors, true sweep counts — is tools/scale_replay.py; this probe
+remains for the anatomy of a mid-size launch (steady-state iteration, tail of the sweep counts)."""
 import sys, os, time
+import json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WHOLE_MS = json.load(open(os.path.join(ROOT, "profiles", "single_gpu.json")))["c4"]["ms_per_step"]   # the whole problem on one GPU
 import __graft_entry__ as ge
 ge.build()
 from insider_amd import api, workloads
@@ -29,6 +34,6 @@ for N in [int(v) for v in args] or [8, 4, 2]:
     run(1, 2, 8, 3.0)
     dt = run(11, 1, 7, w.lam)
     pr = ds.profile()
-    print(f"cd_split={split} c4 / {N}: {p // N} genes: {dt / 11 * 1e3:.3f} ms per outer iteration ({11 / dt:.1f} it/s); ideal from the whole problem: {16.5 / N:.3f} ms; "
+    print(f"cd_split={split} c4 / {N}: {p // N} genes: {dt / 11 * 1e3:.3f} ms per outer iteration ({11 / dt:.1f} it/s); whole problem / N ({WHOLE_MS:.2f} ms per iteration on one GPU, profiles/single_gpu.json): {WHOLE_MS / N:.3f} ms; "
           f"cd {pr['cd_ms'] / 11:.3f} ms, statistics {pr['col_stats_ms'] / 11:.3f} ms per iteration", flush=True)
     ds.close()
