@@ -508,8 +508,9 @@ def main():
                          "78.6 TF f64 matrix peak; issued back to back from four waves per SIMD the 16x16x4 form sustains 0.60 of that peak on "
                          "this part (matrix unit busy 0.60 at 2.39 GHz), the 4x4x4 form 0.93 - 0.95 (tools/ubench_mfma4.hip); the per-entry "
                          "list form of the same statistics (option col_factored = 0) is the streaming-equivalent kernel")},
-            "cd_kernel": {"kernel": ("k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch per coordinate, longest-first gene order)"
-                                     if K <= 32 else ("k_cd_cols_reg<3, .> (32 < K <= 48: the same kernel with three coordinate slots per lane, the third slot's Gram columns in LDS: 7 VALU + 1 LDS read per step, two waves per SIMD)"
+            "cd_kernel": {"kernel": ("k_cd_cols_reg (elastic-net coordinate sweeps: 4 genes per wave, Gram matrix in VGPRs, computed-jump dispatch through absolute "
+                                      "successor addresses, blocks of two coordinate steps where consecutive coordinates share a slot [option cd_pairs], longest-first gene order)"
+                                     if K <= 30 else "k_cd_cols_reg<2, 32> (K = 31, 32: one step per block, 32-bit block offsets)" if K <= 32 else ("k_cd_cols_reg<3, .> (32 < K <= 48: the same kernel with three coordinate slots per lane, the third slot's Gram columns in LDS: 7 VALU + 1 LDS read per step, two waves per SIMD)"
                                                       if K <= 48 else "k_cd_cols<64, 1> (K > 48: one gene per wavefront, Gram matrix in LDS, v_readlane broadcasts)")),
                           "avg_launch_ms": cd_ms, "traffic": tr_cd,
                           "sweeps_per_gene_per_iter": prof["sweeps"] / max(prof["cd_launches"], 1) / p_loc,
@@ -527,12 +528,11 @@ def main():
                           "valu_issue_model_clock_GHz": cd_clock / 1e9,
                           "valu_busy_measured": cd_issue.get("valu_busy_of_resident_simd_time"),
                           "issue_counters": cd_issue or None, "issue_counters_note": inote,
-                          "bound_note": ("one computed jump per coordinate step, three waves per SIMD (161 VGPRs at K = 30): a chain of jump-dispatched "
-                                         "blocks of the step's shape paces per WAVE (tools/ubench8.hip: 27 ns per block for a lone wave, 54 - 55 ns per "
-                                         "wave at 3 and at 4 waves per SIMD = 18.1 / 13.7 ns per SIMD, table sizes 2 ... 64 KB alike) against 13 ns of "
-                                         "vector issue per step; A/B on one box (profiles/r04/exp_quick): a sweep with 25 fewer vector instructions is "
-                                         "slower, one taken branch fewer per sweep (33 -> 32) is 0.8 % faster, a third fewer jumps (blocks of two steps) "
-                                         "gain nothing at full occupancy (DESIGN.md 4.2, 9)"),
+                          "bound_note": ("taken branches, not instructions: three waves per SIMD (161 VGPRs at K = 30) and a computed jump per block.  A/B on "
+                                         "one box in round 5 (profiles/r05/exp): one scalar instruction fewer per step (absolute successor addresses: 9 "
+                                         "instead of 10) changes nothing at K = 30 (+2 - 3 % where waves are alone, c1 / c2); a third fewer jumps (blocks of "
+                                         "two steps, out of line: ~20 jumps per sweep instead of 30) is 4.5 % fewer sweep-kernel ms at c3 and 6 % at c1; "
+                                         "fewer look-ahead touches of the next order row are 5 % slower (DESIGN.md 4.2)"),
                           "share_of_wall": prof["cd_ms"] / (dt * 1e3),
                           # the reference's sweep loop has no cap (src/coordinate_descent.cpp:86-114): solves this call ended
                           # at the library's max_sweeps without convergence (must be 0), and the longest solve
@@ -544,9 +544,19 @@ def main():
         }
         if world > 1:      # the same problem on ONE GPU, from this repository's own single-GPU run (not measured in this job)
             try:
-                base = json.load(open(os.path.join(ROOT, "profiles", "single_gpu.json"))).get(name)
+                sj = json.load(open(os.path.join(ROOT, "profiles", "single_gpu.json")))
+                # (the entry measured with THIS command's steps / warm-up when there is one: the cold start weighs differently)
+                base = sj.get(f"{name}_s{args.steps}w{args.warmup}") or sj.get(name)
                 if base:
                     out["config"]["single_gpu_same_problem"] = base
+                proj = json.load(open(os.path.join(ROOT, "profiles", "r05", "scale_projection.json")))
+                if name == "c4" and str(world) in proj.get("N", {}):
+                    pj = proj["N"][str(world)]["projection"]["assumed"]
+                    out["config"]["projected_before_this_run"] = {
+                        "value_it_per_s": pj["value_it_per_s"], "speedup_vs_single_gpu": pj["speedup_vs_single_gpu"],
+                        "source": ("profiles/r05/scale_projection.json (tools/scale_replay.py: every rank's slab replayed on ONE GPU with the global "
+                                   f"level equations, bulk-synchronous sum, all-reduce priced at {pj['alpha_us']} us + bytes / {pj['link_GBs']} GB/s — an "
+                                   "assumption, no multi-GPU box in the build pipeline; command --steps 20 --warmup 5)")}
             except Exception:
                 pass
         if args.grid and world == 1:

@@ -924,7 +924,8 @@ def test_device_order_table_matches_golden(K, pairs):
                     base = exit_addr - 64 * kmax
                     W, walk, cur, jumps = kmax - 16, [], int(pr[0]), 0
                     pbase = 0
-                                    def decode(addr, pb):
+
+                    def decode(addr, pb):
                         idx, rem = divmod(addr - pb, 128)
                         if rem or idx < 0:
                             return None
