@@ -119,8 +119,9 @@ struct insider_hip_handle {
     double *lvl_sum_all = nullptr;    // [SLcat][STAT + 2 KP + 2]: the level records of every covariate
     bool w_ready = false;
     double *gram_part2 = nullptr, *sc_part2 = nullptr;   // partial-sum buffers of the side-stream products
-    hipEvent_t ev_a_ready = nullptr, ev_qfull = nullptr;
+    hipEvent_t ev_a_ready = nullptr, ev_qfull = nullptr, ev_qheld = nullptr;
     bool qfull_pending = false;
+    bool qheld_pending = false;       // Qheld = S^held A of the factored column statistics is being formed on side3 (phase_R)
     int64_t n = 0, p = 0, ldn = 0, ldp = 0;
     int c = 0, SL = 0, SLP = 0;   // SL: rows of the stacked row factors = all levels of all covariates + m
     int m = 0, SLcat = 0;          // continuous covariates (columns of ctns_confounder) and the categorical level total
@@ -243,6 +244,10 @@ struct insider_hip_handle {
 };
 
 namespace {
+
+// events that order the handle's own streams against each other on ONE device: no timing, and no system-scope fence — what one
+// stream's kernels wrote must reach the other stream's kernels (device scope: every kernel boundary does that), not the host
+constexpr unsigned EV_SYNC = hipEventDisableTiming | hipEventDisableSystemFence;
 
 constexpr int MM_SLAB = 128;  // rows per partial of the reduction products (insider_mm.hpp)
 
@@ -542,7 +547,8 @@ int launch_build_R(insider_hip_handle *h)
 // R, R'R and Qfull from the current row factors (src/optimize.cpp:365-369 and the Xty of :222,235 via level sums)
 // use_side: Qfull, which only the column solve reads, is formed on the side stream next to R'R and the column statistics
 // r_is_current: the row updates have just rebuilt R (every row_update() ends with k_build_R): do not build it again
-int phase_R(insider_hip_handle *h, bool use_side = false, bool r_is_current = false)
+bool use_col_factored(const insider_hip_handle *h);
+int phase_R(insider_hip_handle *h, bool use_side = false, bool r_is_current = false, bool want_qheld = false)
 {
     if (use_side) {
         HIPCHECK(hipEventRecord(h->ev_a_ready, h->stream));
@@ -551,6 +557,14 @@ int phase_R(insider_hip_handle *h, bool use_side = false, bool r_is_current = fa
         if (rq) return rq;
         HIPCHECK(hipEventRecord(h->ev_qfull, h->side));
         h->qfull_pending = true;
+        // ... and so is Qheld = S^held A, which the factored column statistics read: on the third stream (idle since the row
+        // phase's C'C), beside R'R on the main one instead of behind it
+        if (want_qheld && h->Qheld && use_col_factored(h)) {
+            HIPCHECK(hipStreamWaitEvent(h->side3, h->ev_a_ready, 0));
+            if (int rh = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld, h->side3)) return rh;
+            HIPCHECK(hipEventRecord(h->ev_qheld, h->side3));
+            h->qheld_pending = true;
+        }
     }
     int rc = r_is_current ? INSIDER_OK : launch_build_R(h);
     if (rc) return rc;
@@ -565,8 +579,10 @@ struct Timer {   // HIP-event pair around one launch on the library's stream (op
     int begin(insider_hip_handle *h, bool on)
     {
         if (!on || !h->profile) return INSIDER_OK;
-        HIPCHECK(hipEventCreate(&e0));
-        HIPCHECK(hipEventCreate(&e1));
+        // timing only: no system-scope fence (the cache write-back and invalidation it brings cost the FOLLOWING kernel ~20 us behind
+        // a statistics launch that has just written 300 MB; nothing reads these events' work from the host)
+        HIPCHECK(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
+        HIPCHECK(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence));
         HIPCHECK(hipEventRecord(e0, h->stream));
         return INSIDER_OK;
     }
@@ -733,7 +749,10 @@ int launch_col_stats(insider_hip_handle *h, bool timed, bool split = false)
     int rc = t.begin(h, timed);
     if (rc) return rc;
     if (use_col_factored(h)) {
-        if ((rc = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld))) return rc;
+        if (h->qheld_pending) {      // formed on side3 since the row factors were final (phase_R)
+            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_qheld, 0));
+            h->qheld_pending = false;
+        } else if ((rc = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld))) return rc;
         ColFacArgs a = h->cf;
         a.K = h->K;
         a.Astack = h->Astack;
@@ -1510,18 +1529,19 @@ hipError_t make_streams(insider_hip_handle *h)
     MS(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     MS(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
     MS(hipStreamCreateWithFlags(&h->lng, hipStreamNonBlocking));
-    MS(hipEventCreateWithFlags(&h->ev_long_go, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_long_done, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_c_ready, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_head, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_a_ready, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_qfull, hipEventDisableTiming));
+    MS(hipEventCreateWithFlags(&h->ev_long_go, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_long_done, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_prep, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_c_ready, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_head, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_a_ready, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_qfull, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_qheld, EV_SYNC));
     h->ev_w.assign((h->c > 0 ? h->c : 1) + h->m, nullptr);
-    for (auto &ev : h->ev_w) MS(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_cd_done, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_side_done, hipEventDisableTiming));
-    MS(hipEventCreateWithFlags(&h->ev_tab, hipEventDisableTiming));
+    for (auto &ev : h->ev_w) MS(hipEventCreateWithFlags(&ev, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_cd_done, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_side_done, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_tab, EV_SYNC));
 #undef MS
     return hipSuccess;
 }
@@ -1529,7 +1549,7 @@ hipError_t make_streams(insider_hip_handle *h)
 void destroy_streams(insider_hip_handle *h)
 {
     for (hipStream_t *st : {&h->side, &h->side2, &h->side3, &h->lng}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
-    for (hipEvent_t *ev : {&h->ev_long_go, &h->ev_long_done, &h->ev_prep, &h->ev_c_ready, &h->ev_head, &h->ev_a_ready, &h->ev_qfull, &h->ev_cd_done,
+    for (hipEvent_t *ev : {&h->ev_long_go, &h->ev_long_done, &h->ev_prep, &h->ev_c_ready, &h->ev_head, &h->ev_a_ready, &h->ev_qfull, &h->ev_qheld, &h->ev_cd_done,
                            &h->ev_side_done, &h->ev_tab}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
     for (auto ev : h->ev_w) if (ev) (void)hipEventDestroy(ev);
     h->ev_w.clear();
@@ -1596,11 +1616,11 @@ int insider_hip_clone(insider_hip_handle *src, insider_hip_handle **out)
     insider_hip_handle *h = new insider_hip_handle(*src);   // every data-set field and option; the rest is reset below
     forget_workspace(h);                                    // (the copied pointers are the source's buffers)
     h->stream = h->side = h->side2 = h->side3 = h->lng = nullptr;
-    h->ev_long_go = h->ev_long_done = h->ev_prep = h->ev_c_ready = h->ev_head = h->ev_a_ready = h->ev_qfull = nullptr;
+    h->ev_long_go = h->ev_long_done = h->ev_prep = h->ev_c_ready = h->ev_head = h->ev_a_ready = h->ev_qfull = h->ev_qheld = nullptr;
     h->ev_cd_done = h->ev_side_done = h->ev_tab = nullptr;
     h->ev_w.clear();
     for (auto *v : {&h->ev_col, &h->ev_row, &h->ev_cd, &h->ev_test}) v->clear();
-    h->side_pending = h->w_ready = h->qfull_pending = h->long_pending = false;
+    h->side_pending = h->w_ready = h->qfull_pending = h->qheld_pending = h->long_pending = false;
     h->comm = nullptr;                                      // a sharded clone joins its own communicator (insider_hip_comm_init)
     for (double &v : h->prof) v = 0.0;
     h->steady_cd_ms = h->steady_col_ms = 0.0;
@@ -2190,6 +2210,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     h->w_ready = false;
     h->side_pending = false;
     h->qfull_pending = false;
+    h->qheld_pending = false;
     h->long_pending = false;
     const int masked = tuning == 1;
     if ((rc = upload_factors(h, A, C, K))) return rc;
@@ -2255,7 +2276,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
             }
         h->w_ready = false;
         // ---- column step (:365-378) -------------------------------------------------------------------------------
-        if ((rc = phase_R(h, true, true))) return rc;
+        if ((rc = phase_R(h, true, true, masked != 0))) return rc;
         const int checkpoint = iter % 10 == 0;
         if (alpha != 0.0 && iter == 0)   // later iterations: built on the side stream while the previous solve ran
             if ((rc = ensure_order_table(h, seed, iter, K, h->max_sweeps, h->order_mode, lambda2 * alpha, nullptr, 0))) return rc;
@@ -2368,7 +2389,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         (void)hipStreamSynchronize(h->side2);
         (void)hipStreamSynchronize(h->side3);
         (void)hipStreamSynchronize(h->lng);
-        h->side_pending = h->qfull_pending = h->w_ready = h->long_pending = false;
+        h->side_pending = h->qfull_pending = h->qheld_pending = h->w_ready = h->long_pending = false;
         if (h->failflag) (void)hipMemset(h->failflag, 0, 4 * sizeof(int));
         clear_events(h);
         g_err = keep;

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 measurement job (one gpurun call): the bench lines of every config, the grids with concurrent grid points, the K range,
+# Measurement job of a round (one gpurun call; tools/round_measure.sh r05): the bench lines of every config, the grids with concurrent grid points, the K range,
 # continuous covariates at size, the issue-counter and traffic passes.  Outputs under gpurun_out/$1 (default r04).
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -16,6 +16,8 @@ for W in c1 c2 c5; do
   $B --workload $W --no-cpu-baseline > $OUT/bench_$W.json 2> $OUT/bench_$W.err || exit 1
 done
 $B --workload c4 --steps 11 --warmup 1 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err || exit 1
+$B --workload c4 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_c4_s20w5.json 2>> $OUT/bench_c4.err || exit 1
+$B --workload c1 --steps 121 --no-cpu-baseline > $OUT/bench_c1_s121.json 2>> $OUT/bench_c1.err || exit 1
 echo "configs done"
 # tune() grids: serial, 2 and 4 grid points at a time (handles of one resident data set)
 for W in c1 c2; do

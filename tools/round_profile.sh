@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 profile job (one gpurun call, AFTER the last source change): rocprofv3 kernel statistics of the default command, the
+# Profile job of a round (one gpurun call, AFTER the last source change; INSIDER_COMMIT=<hash> tools/round_profile.sh r05): rocprofv3 kernel statistics of the default command, the
 # FETCH / WRITE passes behind profiles/traffic.json, the SQ issue-counter passes behind profiles/issue.json, the steady-state
-# timeline, the c4 / 8 slab, concurrent grids.  Outputs under gpurun_out/$1 (default r04); tools/collect_r04.sh copies them.
+# timeline, the c4 / 8 slab, concurrent grids.  Outputs under gpurun_out/$1 (default r04); tools/collect_round.sh copies them.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
