@@ -146,42 +146,133 @@ struct RegState {
 #define REG_PAIRS_CLOSE ".p2align 7\n s_endpgm\n .popsection\n .purgem INSIDER_CD_STEP2\n .purgem INSIDER_CD_STEP1\n"
 // the row's pairs into s[REG_PB : 97] : 2 (KMAX + 1) dwords from byte REG_ORDER_OFF of the order-table row, in the largest aligned
 // pieces (the destination of an x4 / x8 / x16 scalar load is 4-aligned: REG_PB is a multiple of 4 for even KMAX)
-#define REG_LOADS_16 "s_load_dwordx16 s[64:79], %[tb], 0x0\n s_load_dwordx16 s[80:95], %[tb], 0x40\n s_load_dwordx2 s[96:97], %[tb], 0x80\n"
-#define REG_LOADS_18 "s_load_dwordx16 s[60:75], %[tb], 0x0\n s_load_dwordx16 s[76:91], %[tb], 0x40\n s_load_dwordx4 s[92:95], %[tb], 0x80\n s_load_dwordx2 s[96:97], %[tb], 0x90\n"
-#define REG_LOADS_20 "s_load_dwordx16 s[56:71], %[tb], 0x0\n s_load_dwordx16 s[72:87], %[tb], 0x40\n s_load_dwordx8 s[88:95], %[tb], 0x80\n s_load_dwordx2 s[96:97], %[tb], 0xa0\n"
-#define REG_LOADS_22 "s_load_dwordx16 s[52:67], %[tb], 0x0\n s_load_dwordx16 s[68:83], %[tb], 0x40\n s_load_dwordx8 s[84:91], %[tb], 0x80\n s_load_dwordx4 s[92:95], %[tb], 0xa0\n s_load_dwordx2 s[96:97], %[tb], 0xb0\n"
-#define REG_LOADS_24 "s_load_dwordx16 s[48:63], %[tb], 0x0\n s_load_dwordx16 s[64:79], %[tb], 0x40\n s_load_dwordx16 s[80:95], %[tb], 0x80\n s_load_dwordx2 s[96:97], %[tb], 0xc0\n"
-#define REG_LOADS_26 "s_load_dwordx16 s[44:59], %[tb], 0x0\n s_load_dwordx16 s[60:75], %[tb], 0x40\n s_load_dwordx16 s[76:91], %[tb], 0x80\n s_load_dwordx4 s[92:95], %[tb], 0xc0\n s_load_dwordx2 s[96:97], %[tb], 0xd0\n"
-#define REG_LOADS_28 "s_load_dwordx16 s[40:55], %[tb], 0x0\n s_load_dwordx16 s[56:71], %[tb], 0x40\n s_load_dwordx16 s[72:87], %[tb], 0x80\n s_load_dwordx8 s[88:95], %[tb], 0xc0\n s_load_dwordx2 s[96:97], %[tb], 0xe0\n"
-#define REG_LOADS_30 "s_load_dwordx16 s[36:51], %[tb], 0x0\n s_load_dwordx16 s[52:67], %[tb], 0x40\n s_load_dwordx16 s[68:83], %[tb], 0x80\n s_load_dwordx8 s[84:91], %[tb], 0xc0\n s_load_dwordx4 s[92:95], %[tb], 0xe0\n s_load_dwordx2 s[96:97], %[tb], 0xf0\n"
+#define REG_LOADS_16(AD) "s_load_dwordx16 s[64:79], " AD "0x0\n s_load_dwordx16 s[80:95], " AD "0x40\n s_load_dwordx2 s[96:97], " AD "0x80\n"
+#define REG_LOADS_18(AD) "s_load_dwordx16 s[60:75], " AD "0x0\n s_load_dwordx16 s[76:91], " AD "0x40\n s_load_dwordx4 s[92:95], " AD "0x80\n s_load_dwordx2 s[96:97], " AD "0x90\n"
+#define REG_LOADS_20(AD) "s_load_dwordx16 s[56:71], " AD "0x0\n s_load_dwordx16 s[72:87], " AD "0x40\n s_load_dwordx8 s[88:95], " AD "0x80\n s_load_dwordx2 s[96:97], " AD "0xa0\n"
+#define REG_LOADS_22(AD) "s_load_dwordx16 s[52:67], " AD "0x0\n s_load_dwordx16 s[68:83], " AD "0x40\n s_load_dwordx8 s[84:91], " AD "0x80\n s_load_dwordx4 s[92:95], " AD "0xa0\n s_load_dwordx2 s[96:97], " AD "0xb0\n"
+#define REG_LOADS_24(AD) "s_load_dwordx16 s[48:63], " AD "0x0\n s_load_dwordx16 s[64:79], " AD "0x40\n s_load_dwordx16 s[80:95], " AD "0x80\n s_load_dwordx2 s[96:97], " AD "0xc0\n"
+#define REG_LOADS_26(AD) "s_load_dwordx16 s[44:59], " AD "0x0\n s_load_dwordx16 s[60:75], " AD "0x40\n s_load_dwordx16 s[76:91], " AD "0x80\n s_load_dwordx4 s[92:95], " AD "0xc0\n s_load_dwordx2 s[96:97], " AD "0xd0\n"
+#define REG_LOADS_28(AD) "s_load_dwordx16 s[40:55], " AD "0x0\n s_load_dwordx16 s[56:71], " AD "0x40\n s_load_dwordx16 s[72:87], " AD "0x80\n s_load_dwordx8 s[88:95], " AD "0xc0\n s_load_dwordx2 s[96:97], " AD "0xe0\n"
+#define REG_LOADS_30(AD) "s_load_dwordx16 s[36:51], " AD "0x0\n s_load_dwordx16 s[52:67], " AD "0x40\n s_load_dwordx16 s[68:83], " AD "0x80\n s_load_dwordx8 s[84:91], " AD "0xc0\n s_load_dwordx4 s[92:95], " AD "0xe0\n s_load_dwordx2 s[96:97], " AD "0xf0\n"
 #define REG_CAT_(a, b) a##b
 #define REG_CAT(a, b) REG_CAT_(a, b)
-// (the next sweep's row is touched one sweep ahead: its four 64-byte lines from REG_ORDER_OFF on are in the scalar cache when that
-// sweep starts; waited for in the exit block)
+// ---- the sweep LOOP as one asm statement (round 5, K <= 30) -------------------------------------------------------------------
+// Not only the sweep but the per-sweep bookkeeping and the loop control are inside the statement: the common path of a sweep
+// never leaves it.  Layout:
+//     entry:   load the successor list of sweep `sw` (row `off` of the order table), touch the row after it; branch to Lgo
+//     Lc:      the table of code blocks (one step each; the two-step blocks live in their own section)
+//     exit block (index KMAX): the exact loss change of the sweep (the instructions the compiler made of the C++ that
+//              stood here until round 4, in its order: same roundings), ++sw, the NEXT sweep's list requested BEFORE the
+//              bookkeeping so that its latency hides behind it (the list load at the start of a sweep was exposed: the
+//              look-ahead touches alone are worth 5 %), the convergence test on the row sums, and
+//              leave (Lout) when a gene may stop or the caller's bound is reached; else fall into
+//     Lgo:     wait for the list, jump into the sweep's first block
+// so a sweep costs its blocks' jumps plus ONE (no back edge).  The rarely taken part — screening violations, parking a finished
+// gene, window sums of a limited pass — stays C++ behind the statement (cd_reg).
+// The row reduction moves 64-bit values as two 32-bit DPP moves (64-bit DPP knows row_newbcast only), and inline asm cannot name
+// the halves of a 64-bit operand: its two temporaries are therefore pinned to v[2:3] / v[4:5].
+#define REG_AD "%[tb0], %[off] offset:"
+#define REG_ROWSTR REG_STR(INSIDER_ORDER_ROW)
 #ifndef INSIDER_REG_TOUCHES
 #define INSIDER_REG_TOUCHES 4
 #endif
 #if INSIDER_REG_TOUCHES == 4
-#define REG_TOUCH                                                                    \
-    "s_load_dword %[sk], %[tb], " REG_STR(INSIDER_ORDER_ROW) "\n"                     \
-    "s_load_dword %[p1], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x40\n"                \
-    "s_load_dword %[p2], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x80\n"                \
-    "s_load_dword %[p3], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0xc0\n"
-#elif INSIDER_REG_TOUCHES == 2
-#define REG_TOUCH                                                                    \
-    "s_load_dword %[sk], %[tb], " REG_STR(INSIDER_ORDER_ROW) "\n"                     \
-    "s_load_dword %[p2], %[tb], " REG_STR(INSIDER_ORDER_ROW) "+0x80\n"
+#define REG_TOUCH                                                     \
+    "s_load_dword %[sk], " REG_AD REG_ROWSTR "\n"                      \
+    "s_load_dword %[p1], " REG_AD REG_ROWSTR "+0x40\n"                 \
+    "s_load_dword %[p2], " REG_AD REG_ROWSTR "+0x80\n"                 \
+    "s_load_dword %[p3], " REG_AD REG_ROWSTR "+0xc0\n"
 #else
 #define REG_TOUCH
 #endif
-#define REG_PROLOGUE                                                                 \
-    REG_CAT(REG_LOADS_, REG_KM)                                                      \
-    "s_waitcnt lgkmcnt(0)\n"                                                         \
-    REG_TOUCH                                                                        \
-    "s_setpc_b64 s[" REG_PB ":" REG_PB "+1]\n"                                        \
-    ".p2align 8\n"                                                                   \
-    "insider_cdtab_" REG_STR(REG_KM) "_%c[who]:\n"                                    \
+#define REG_LOOP_ENTRY                                                \
+    REG_CAT(REG_LOADS_, REG_KM)(REG_AD) REG_TOUCH                     \
+    "s_branch Lgo%=\n"                                                \
+    ".p2align 8\n"                                                    \
+    "insider_cdtab_" REG_STR(REG_KM) "_%c[who]:\n"                     \
     "Lc%=:\n"
+#define REG_DPP4(D0, D1, S0, S1, CTRL)                                                          \
+    "v_mov_b32_dpp " D0 ", " S0 " " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"           \
+    "v_mov_b32_dpp " D1 ", " S1 " " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// sum over each 16-lane row of la * t (t in v[2:3]) -> v[2:3]: row16_sum(la * t) as the compiler contracted it.  (The tails keep
+// three of their values in the pinned pairs and in dn, which is free between sweeps: the loop needs no more registers than the C++
+// bookkeeping took.)
+#define REG_ROWSUM                                                    \
+    "v_mul_f64 v[4:5], %[las], v[2:3]\n"                              \
+    "s_nop 1\n"                                                       \
+    REG_DPP4("v4", "v5", "v4", "v5", "quad_perm:[1,0,3,2]")           \
+    "v_fmac_f64 v[4:5], %[las], v[2:3]\n"                             \
+    "s_nop 1\n"                                                       \
+    REG_DPP4("v2", "v3", "v4", "v5", "quad_perm:[2,3,0,1]")           \
+    "v_add_f64 v[2:3], v[4:5], v[2:3]\n"                              \
+    "s_nop 1\n"                                                       \
+    REG_DPP4("v4", "v5", "v2", "v3", "row_half_mirror")               \
+    "v_add_f64 v[2:3], v[2:3], v[4:5]\n"                              \
+    "s_nop 1\n"                                                       \
+    REG_DPP4("v4", "v5", "v2", "v3", "row_mirror")                    \
+    "v_add_f64 v[2:3], v[2:3], v[4:5]\n"
+// (stash offsets: D at 0, the sweep-start beta at SA * 8 = 1024, the sweep-start what at 2048; second slot + 512: reg_sa)
+#define REG_NEXT_LIST                                                 \
+    "s_add_i32 %[sw], %[sw], 1\n"                                     \
+    "s_and_b32 %[off], %[sw], (" REG_STR(INSIDER_PERM_PERIOD) "-1)\n"  \
+    "s_mulk_i32 %[off], " REG_ROWSTR "\n"                             \
+    "s_waitcnt lgkmcnt(0)\n"                                          \
+    REG_CAT(REG_LOADS_, REG_KM)(REG_AD) REG_TOUCH
+#define REG_LOOP_END                                                  \
+    "v_add_f64 %[aw], %[aw], |v[2:3]|\n"                              \
+    "v_cmp_nlt_f64_e64 vcc, %[tol], |v[2:3]|\n"                       \
+    "s_nop 0\n"                                                       \
+    "s_and_b64 %[cand], vcc, %[run]\n"                                \
+    "s_cbranch_scc1 Lout%=\n"                                         \
+    "s_cmp_lt_i32 %[sw], %[stop]\n"                                   \
+    "s_cbranch_scc0 Lout%=\n"                                         \
+    "Lgo%=:\n"                                                        \
+    "s_waitcnt lgkmcnt(0)\n"                                          \
+    "s_setpc_b64 s[" REG_PB ":" REG_PB "+1]\n"                        \
+    "Lout%=:\n"                                                       \
+    "s_waitcnt lgkmcnt(0)\n"
+#define REG_TAIL2                                                     \
+    "ds_read_b64 %[t0], %[la]\n"                                      \
+    "ds_read_b64 %[t1], %[la] offset:512\n"                           \
+    "ds_read_b64 v[2:3], %[la] offset:1024\n"                          \
+    "ds_read_b64 %[t3], %[la] offset:1536\n"                          \
+    "ds_read_b64 %[t4], %[la] offset:2048\n"                          \
+    "ds_read_b64 v[4:5], %[la] offset:2560\n"                          \
+    REG_NEXT_LIST                                                     \
+    "v_fma_f64 %[t0], %[b0], %[t0], -%[h0]\n"                         \
+    "v_fma_f64 %[t1], %[b1], %[t1], -%[h1]\n"                         \
+    "v_add_f64 %[t4], %[t0], %[t4]\n"                                 \
+    "v_add_f64 %[dn], %[b0], -v[2:3]\n"                                \
+    "v_add_f64 %[t4], %[t4], 1.0\n"                                   \
+    "v_add_f64 v[4:5], %[t1], v[4:5]\n"                                 \
+    "v_add_f64 v[2:3], |%[b0]|, -|v[2:3]|\n"                            \
+    "v_fma_f64 %[t4], %[dn], %[t4], 0\n"                              \
+    "v_add_f64 %[dn], %[b1], -%[t3]\n"                                \
+    "v_add_f64 v[4:5], v[4:5], 1.0\n"                                   \
+    "v_add_f64 %[t3], |%[b1]|, -|%[t3]|\n"                            \
+    "v_fmac_f64 %[t4], %[dn], v[4:5]\n"                                \
+    "v_add_f64 v[2:3], v[2:3], %[t3]\n"                                 \
+    "ds_write_b64 %[la], %[b0] offset:1024\n"                         \
+    "ds_write_b64 %[la], %[b1] offset:1536\n"                         \
+    "ds_write_b64 %[la], %[t0] offset:2048\n"                         \
+    "ds_write_b64 %[la], %[t1] offset:2560\n"                         \
+    "v_add_f64 v[2:3], v[2:3], %[t4]\n"                                 \
+    REG_ROWSUM REG_LOOP_END
+#define REG_TAIL1                                                     \
+    "ds_read_b64 %[t0], %[la]\n"                                      \
+    "ds_read_b64 v[2:3], %[la] offset:1024\n"                          \
+    "ds_read_b64 v[4:5], %[la] offset:2048\n"                          \
+    REG_NEXT_LIST                                                     \
+    "v_fma_f64 %[t0], %[b0], %[t0], -%[h0]\n"                         \
+    "v_add_f64 v[4:5], %[t0], v[4:5]\n"                                 \
+    "v_add_f64 %[dn], %[b0], -v[2:3]\n"                                \
+    "ds_write_b64 %[la], %[b0] offset:1024\n"                         \
+    "ds_write_b64 %[la], %[t0] offset:2048\n"                         \
+    "v_add_f64 v[4:5], v[4:5], 1.0\n"                                   \
+    "v_add_f64 v[2:3], |%[b0]|, -|v[2:3]|\n"                            \
+    "v_fma_f64 v[4:5], %[dn], v[4:5], 0\n"                              \
+    "v_add_f64 v[2:3], v[2:3], v[4:5]\n"                                 \
+    REG_ROWSUM REG_LOOP_END
 #define REG_EPILOGUE(NBLK) REG_ORG(NBLK) " s_waitcnt lgkmcnt(0)\n"   /* exit block */
 #define REG_S48_63 "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
 #define REG_S64_97 "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
@@ -217,39 +308,52 @@ struct RegState {
 #define REG_HB_30(F) REG_HB_28(F) F(28, 12) F(29, 13)
 #define REG_HB_32(F) REG_HB_30(F) F(30, 14) F(31, 15)
 
-// tb: this sweep's successor pairs (order-table row + REG_ORDER_OFF).  WHO: which kernel the sweep is inlined into (0 = the column
-// update k_cd_cols_reg, 1 = the stand-alone batch k_cd_batch_reg): part of the NAMED label of the table of blocks, whose address
-// reg_code_base() takes from another asm statement of the same kernel
+// The sweep loop (above).  tb0: row 0 of the order table + REG_ORDER_OFF; off: byte offset of sweep `sw`'s row (in / out); sw: the
+// sweep counter (in / out: the statement leaves with the number of sweeps done); stop: leave when sw reaches it; run: lane mask
+// of the genes still running; lds: LDS byte address of this lane's first stash cell; accw: running sum of |loss change| (the
+// windows of a limited pass: the caller resets and files it); dl: the last sweep's loss change (row sum); cand: lanes of running
+// genes whose |loss change| <= tol in the last sweep (0: the statement left because sw == stop).
+// WHO: which kernel the loop is inlined into (0 = the column update k_cd_cols_reg, 1 = the stand-alone batch k_cd_batch_reg): part
+// of the NAMED label of the table of blocks, whose address reg_code_base() takes from another asm statement of the same kernel;
+// the column-update kernel also carries the blocks of two steps.
+#define REG_LOOP_OUTS2                                                                                                     \
+    [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), [aw] "+v"(accw), [dl] "=&{v[2:3]}"(dl), \
+        [rb] "=&{v[4:5]}"(rb), [dn] "=&v"(dn), [t0] "=&v"(t0), [t1] "=&v"(t1), [t3] "=&v"(t3), [t4] "=&v"(t4), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand), [sk] "=&s"(sk), [p1] "=&s"(p1),   \
+        [p2] "=&s"(p2), [p3] "=&s"(p3)
+#define REG_LOOP_INS_TAIL                                                                                                  \
+    [tb0] "s"(tb0), [lm] "s"(lm), [run] "s"(run), [las] "s"(la), [tol] "s"(tol), [stop] "s"(stop), [la] "v"(lds), [who] "i"(WHO)
+#define REG_LOOP_CLOBBERS "vcc", REG_CLOBBERS
 #if defined(__HIP_DEVICE_COMPILE__)   // gfx950 assembly: hipcc's host pass must not parse it
 #define REG_DEFINE_SWEEP2(KMAX)                                                                                          \
     template <int WHO>                                                                                                   \
-    __device__ __forceinline__ void reg_sweep(RegState<2> &S, const double (&G)[2][KMAX], const uint32_t *tb)            \
+    __device__ __forceinline__ void reg_sweeps(RegState<2> &S, const double (&G)[2][KMAX], const uint32_t *tb0, int &off, \
+                                               int &sw, int stop, uint64_t run, double la, double tol, uint32_t lds,     \
+                                               double &accw, double &dl, uint64_t &cand)                                 \
     {                                                                                                                    \
-        double dn;                                                                                                       \
+        double dn, rb, t0, t1, t3, t4;                                                                                   \
         int sk, p1, p2, p3;                                                                                              \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
         if constexpr (WHO == 0)                                                                                          \
-            asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                   \
+            asm volatile(REG_LOOP_ENTRY REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_ORG(KMAX) REG_TAIL2            \
                              REG_PAIRS_OPEN REG_LIST_LO(REGP_ROW_LO) REG_HB_##KMAX(REGP_ROW_HI) REG_PAIRS_CLOSE               \
-                         : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]),             \
-                           [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3)               \
+                         : REG_LOOP_OUTS2                                                                                \
                          : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(  \
                                S.tau[0]),                                                                                \
-                           [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)                                \
-                         : REG_CLOBBERS);                                                                                \
+                           [i1] "v"(S.tau[1]), REG_LOOP_INS_TAIL                                                         \
+                         : REG_LOOP_CLOBBERS);                                                                           \
         else                                                                                                             \
-            asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_EPILOGUE(KMAX)                   \
-                         : [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]),             \
-                           [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3)               \
+            asm volatile(REG_LOOP_ENTRY REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_ORG(KMAX) REG_TAIL2            \
+                         : REG_LOOP_OUTS2                                                                                \
                          : REG_LIST_LO(REG_GA) REG_HI_##KMAX(REG_GA) REG_LIST_LO(REG_GB) REG_HI_##KMAX(REG_GB)[i0] "v"(  \
                                S.tau[0]),                                                                                \
-                           [i1] "v"(S.tau[1]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)                                \
-                         : REG_CLOBBERS);                                                                                \
+                           [i1] "v"(S.tau[1]), REG_LOOP_INS_TAIL                                                         \
+                         : REG_LOOP_CLOBBERS);                                                                           \
     }
 #else
-#define REG_DEFINE_SWEEP2(KMAX) \
-    template <int WHO>          \
-    __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][KMAX], const uint32_t *) {}
+#define REG_DEFINE_SWEEP2(KMAX)                                                                                          \
+    template <int WHO>                                                                                                   \
+    __device__ __forceinline__ void reg_sweeps(RegState<2> &, const double (&)[2][KMAX], const uint32_t *, int &, int &, int, \
+                                               uint64_t, double, double, uint32_t, double &, double &, uint64_t &) {}
 #endif
 #define REG_KM 18
 #define REG_PBN 60
@@ -286,6 +390,7 @@ REG_DEFINE_SWEEP2(28)
 REG_DEFINE_SWEEP2(30)
 #undef REG_KM
 #undef REG_PBN
+
 // KMAX = 32 (K = 31, 32) keeps the successor list as 32-bit block OFFSETS: its 33 pairs would take s34 ... s99, every scalar
 // register between the reserved s32 and s100, and the kernel (168 VGPRs for 128 matrix registers) then spills a vector register
 // under the step's narrowed exec mask.  The list is loaded into s[64:97] (dword 0 = first block, dword 1 + k = the block after
@@ -339,25 +444,28 @@ __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][32]
 
 #define REG_KM 16
 #define REG_PBN 64
+#define REG_LOOP_OUTS1                                                                                                      \
+    [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [aw] "+v"(accw), [dl] "=&{v[2:3]}"(dl), [rb] "=&{v[4:5]}"(rb), [dn] "=&v"(dn),  \
+        [t0] "=&v"(t0), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand),                                                  \
+        [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3)
 template <int WHO>
-__device__ __forceinline__ void reg_sweep(RegState<1> &S, const double (&G)[1][16], const uint32_t *tb)
+__device__ __forceinline__ void reg_sweeps(RegState<1> &S, const double (&G)[1][16], const uint32_t *tb0, int &off, int &sw, int stop,
+                                           uint64_t run, double la, double tol, uint32_t lds, double &accw, double &dl, uint64_t &cand)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double dn;
+    double dn, rb, t0;
     int sk, p1, p2, p3;
     const uint64_t lm = 0x0001000100010001ull;
     if constexpr (WHO == 0)
-        asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16) REG_PAIRS_OPEN REG_LIST_LO(REGP1_ROW_LO) REG_PAIRS_CLOSE
-                     : [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
-                       [p2] "=&s"(p2), [p3] "=&s"(p3)
-                     : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)
-                     : REG_CLOBBERS);
+        asm volatile(REG_LOOP_ENTRY REG_LIST_LO(REG_BLOCK1) REG_ORG(16) REG_TAIL1 REG_PAIRS_OPEN REG_LIST_LO(REGP1_ROW_LO) REG_PAIRS_CLOSE
+                     : REG_LOOP_OUTS1
+                     : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), REG_LOOP_INS_TAIL
+                     : REG_LOOP_CLOBBERS);
     else
-        asm volatile(REG_PROLOGUE REG_LIST_LO(REG_BLOCK1) REG_EPILOGUE(16)
-                     : [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [dn] "=&v"(dn), [sk] "=&s"(sk), [p1] "=&s"(p1),
-                       [p2] "=&s"(p2), [p3] "=&s"(p3)
-                     : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), [tb] "s"(tb), [lm] "s"(lm), [who] "i"(WHO)
-                     : REG_CLOBBERS);
+        asm volatile(REG_LOOP_ENTRY REG_LIST_LO(REG_BLOCK1) REG_ORG(16) REG_TAIL1
+                     : REG_LOOP_OUTS1
+                     : REG_LIST_LO(REG_GA)[i0] "v"(S.tau[0]), REG_LOOP_INS_TAIL
+                     : REG_LOOP_CLOBBERS);
 #endif
 }
 #undef REG_KM
@@ -693,55 +801,78 @@ __device__ __forceinline__ int cd_reg(RegState<SLOTS> S, const double (&G)[reg_r
 #endif
     // the table holds one period of the order sequence: sweep s reads row s mod INSIDER_PERM_PERIOD (include/insider_perm.h)
     const uint32_t *tb0 = reinterpret_cast<const uint32_t *>(order + (SLOTS == 3 ? REG3_ORDER_OFF : REG_ORDER_OFF));
-    const uint32_t *tb = tb0 + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * (ORDER_ROW / 4);
-    while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
-        // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
-        if constexpr (SLOTS == 3) reg_sweep<WHO>(S, G, tb, pla);
-        else reg_sweep<WHO>(S, G, tb);
-        ++sweep;
-        tb = (sweep & (int)(INSIDER_PERM_PERIOD - 1)) ? tb + ORDER_ROW / 4 : tb0;
-        // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
-        double acc = 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
-            const double beta0 = s_b[64 * u];
-            const double w1 = fma(S.beta[u], s_d[64 * u], -S.y[u]);
-            acc = fma(S.beta[u] - beta0, (w1 + s_w[64 * u]) + 1.0, acc);
-            acc1 += fabs(S.beta[u]) - fabs(beta0);
-            s_b[64 * u] = S.beta[u];
-            s_w[64 * u] = w1;
-        }
-        const double dloss = row16_sum(la * (acc1 + acc));
-        if (__builtin_expect(sweep > win, 0)) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);   // wave-uniform, limited passes only
-        const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
-        if (cand != 0) {                                                                    // wave-uniform, rarely taken
-            // lane masks are formed here, from a laundered lane id, and not kept in registers across the sweeps
-            int ln = lane;
+    // ---- genes that may stop (:114-124): wave-uniform, rarely taken ----------------------------------------------------------
+    auto candidates = [&](uint64_t cand) {
+        // lane masks are formed here, from a laundered lane id, and not kept in registers across the sweeps
+        int ln = lane;
 #if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(ln));
+        asm volatile("" : "+v"(ln));
 #endif
-            const uint64_t rowmask = 0xffffull << (ln & 48);
-            const bool mine = (cand >> ln) & 1ull;
-            bool anyv = false;
-            if (mine) {
+        const uint64_t rowmask = 0xffffull << (ln & 48);
+        const bool mine = (cand >> ln) & 1ull;
+        bool anyv = false;
+        if (mine) {
 #pragma unroll
-                for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
-                    const bool viol = gene_ok && 16 * u + i < K && S.tau[u] == 0.0 && fabs(fma(S.y[u], two_la, -la)) > la;
-                    if (viol) S.tau[u] = two_la * s_ri[64 * u];                             // :123
-                    anyv = anyv || viol;
-                }
+            for (int u = 0; u < SLOTS; ++u) {   // :118-119: excluded coordinates have beta = 0, so grad = -h
+                const bool viol = gene_ok && 16 * u + i < K && S.tau[u] == 0.0 && fabs(fma(S.y[u], two_la, -la)) > la;
+                if (viol) S.tau[u] = two_la * s_ri[64 * u];                             // :123
+                anyv = anyv || viol;
             }
-            const bool finish = mine && (__ballot(anyv) & rowmask) == 0;                    // :120-121
-            if (finish) {   // park the row: zero increments from now on
-                my_sweeps = sweep;
+        }
+        const bool finish = mine && (__ballot(anyv) & rowmask) == 0;                    // :120-121
+        if (finish) {   // park the row: zero increments from now on
+            my_sweeps = sweep;
 #pragma unroll
-                for (int u = 0; u < SLOTS; ++u) {
-                    s_out[64 * u] = S.beta[u];
-                    S.beta[u] = 0.0;
-                    S.tau[u] = 0.0;
-                }
+            for (int u = 0; u < SLOTS; ++u) {
+                s_out[64 * u] = S.beta[u];
+                S.beta[u] = 0.0;
+                S.tau[u] = 0.0;
             }
-            runm &= ~__ballot(finish);
+        }
+        runm &= ~__ballot(finish);
+    };
+    if constexpr (SLOTS < 3 && reg_pairs(KMAX)) {
+        // K <= 30: the sweep, the loss change of the sweep (:112-114) and the loop control are ONE asm statement (reg_sweeps); it
+        // comes back when a running gene's |loss change| <= tol or at `bound` — the pass limit, or a window edge of a limited
+        // pass, whose two sums of |loss change| over W sweeps (the remaining-length estimate below) it accumulates in accw
+        typedef __attribute__((address_space(3))) const double lds_cd;
+        const uint32_t lds = (uint32_t)(uintptr_t)(lds_cd *)s_d;
+        int off = (sweep & (int)(INSIDER_PERM_PERIOD - 1)) * ORDER_ROW;
+        double accw = 0.0, dloss = 0.0;
+        uint64_t cand = 0;
+        while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
+            int bound = stop;
+            if (sweep < win) bound = win < stop ? win : stop;
+            else if (sweep < win + W) bound = win + W;
+            reg_sweeps<WHO>(S, G, tb0, off, sweep, bound, runm, la, tol, lds, accw, dloss, cand);
+            if (sweep == win) accw = 0.0;                          // window 0: sweeps win + 1 ... win + W
+            else if (sweep == win + W) { s_acc[0] = accw; accw = 0.0; }   // window 1: the rest of the pass
+            if (cand != 0) candidates(cand);
+        }
+        s_acc[64] = accw;
+    } else {
+        const uint32_t *tb = tb0 + (size_t)(sweep & (int)(INSIDER_PERM_PERIOD - 1)) * (ORDER_ROW / 4);
+        while (runm != 0 && sweep < stop) {   // the sweep cap / pass limit is the loop bound: genes still running then are handled below
+            // ---- the sweep (:91-110) -----------------------------------------------------------------------------------
+            if constexpr (SLOTS == 3) reg_sweep<WHO>(S, G, tb, pla);
+            else if constexpr (!reg_pairs(KMAX)) reg_sweep<WHO>(S, G, tb);
+            ++sweep;
+            tb = (sweep & (int)(INSIDER_PERM_PERIOD - 1)) ? tb + ORDER_ROW / 4 : tb0;
+            // ---- loss change of the sweep (:112-114), per gene ------------------------------------------------------------
+            double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) {
+                const double beta0 = s_b[64 * u];
+                const double w1 = fma(S.beta[u], s_d[64 * u], -S.y[u]);
+                acc = fma(S.beta[u] - beta0, (w1 + s_w[64 * u]) + 1.0, acc);
+                acc1 += fabs(S.beta[u]) - fabs(beta0);
+                s_b[64 * u] = S.beta[u];
+                s_w[64 * u] = w1;
+            }
+            const double dloss = row16_sum(la * (acc1 + acc));
+            if (__builtin_expect(sweep > win, 0)) s_acc[sweep > win + W ? 64 : 0] += fabs(dloss);   // wave-uniform, limited passes only
+            const uint64_t cand = __ballot(!(fabs(dloss) > tol)) & runm;                        // :114 genes that may stop now
+            if (cand != 0) candidates(cand);
         }
     }
     if ((runm >> lane) & 1ull) {   // stopped by the sweep cap, or by the end of a limited pass

@@ -160,19 +160,18 @@ def test_sweep_kernels_do_not_spill(tmp_path, lib):
         scratch = [t for _a, t, _r in ins if t.startswith(("scratch_", "buffer_load", "buffer_store"))]
         if kmax <= 30:
             assert not scratch, (head, scratch[:4])
-        # the sweep's prologue starts with the loads of the successor list: absolute address pairs into s[96 - 2 KMAX : 97] for
-        # KMAX <= 30 (round 5), 32-bit offsets into s[64:97] (KMAX = 32) / s[48:96] (three slots: four loads), followed there by
-        # the s_getpc_b64 that anchors the table of code blocks
+        # K <= 30 (round 5): the whole sweep LOOP is one asm statement — the successor list (absolute address pairs into
+        # s[96 - 2 KMAX : 97]) is loaded at its entry and again in the exit block, for the next sweep; KMAX = 32 / three slots:
+        # one statement per sweep, 32-bit offsets into s[64:97] / s[48:96], followed by the s_getpc_b64 that anchors the table
         pb = 96 - 2 * kmax
         first = f"s_load_dwordx16 s[{pb}:{pb + 15}]" if kmax <= 30 else ("s_load_dwordx16 s[48:63]" if kmax > 32 else "s_load_dwordx16 s[64:79]")
         sites = [i for i, (_, t, _r) in enumerate(ins) if t.startswith(first)]
         if "k_cd_cols_reg" in head and "ELb0E" in head:
             assert not sites and not any(t.startswith("s_setpc_b64") for _a, t, _r in ins), head   # the evaluation kernels have no sweep loop
             continue
-        assert len(sites) == 1, (head, len(sites))
-        if kmax > 30:
-            assert ins[sites[0] + (4 if kmax > 32 else 3)][1].startswith("s_getpc_b64 s[98:99]"), head
-        else:      # one computed jump per code block and one into the first block, each on its own register pair; no address add
+        if kmax <= 30:
+            assert len(sites) == 2, (head, len(sites))
+            # one computed jump per code block and one into the first block, each on its own register pair; no address add
             jumps = [t for _a, t, _r in ins if t.startswith("s_setpc_b64 s[")]
             assert len(set(jumps)) == kmax + 1, (head, len(set(jumps)))
             # the column-update kernel also carries its blocks of two steps (a section of their own behind insider_cdpair_<KMAX>;
@@ -180,6 +179,18 @@ def test_sweep_kernels_do_not_spill(tmp_path, lib):
             npair = 256 + (kmax - 16) ** 2 if "k_cd_cols_reg" in head else 0
             assert len(jumps) in (kmax + 1, kmax + 1 + npair), (head, len(jumps))
             assert not any(t.startswith("s_add_u32 vcc_lo") for _a, t, _r in ins), head
+            # the loop body = from the table of blocks to the jump back into the first block (label Lgo): no scratch traffic, no
+            # accumulation registers, no SGPR spill traffic (v_readlane / v_writelane) on the path of a sweep
+            i0 = next(i for i, (_a, t, _r) in enumerate(ins) if t.startswith("s_lshl_b64 exec"))
+            i1 = max(i for i, (_a, t, _r) in enumerate(ins[: sites[1] + 200]) if t.startswith(f"s_setpc_b64 s[{pb}:{pb + 1}]"))
+            body = [t for _a, t, _r in ins[i0: i1 + 1]]
+            assert len(body) > 9 * min(kmax, 30) and i1 > sites[1], (head, len(body))
+            bad = [t for t in body if t.startswith(("scratch_", "buffer_load", "buffer_store", "v_accvgpr", "v_readlane", "v_writelane"))]
+            assert not bad, (head, bad[:4])
+            loops += 1
+            continue
+        assert len(sites) == 1, (head, len(sites))
+        assert ins[sites[0] + (4 if kmax > 32 else 3)][1].startswith("s_getpc_b64 s[98:99]"), head
         a0 = ins[sites[0]][0]
         # the loop's back edge: the first branch after the sweep whose target lies at or shortly before the sweep's first load
         back = None
