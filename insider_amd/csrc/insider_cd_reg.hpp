@@ -186,7 +186,7 @@ struct RegState {
 #define REG_TOUCH
 #endif
 #define REG_LOOP_ENTRY                                                \
-    REG_CAT(REG_LOADS_, REG_KM)(REG_AD) REG_TOUCH                     \
+    REG_LDS REG_CAT(REG_LOADS_, REG_KM)(REG_AD) REG_TOUCH             \
     "s_branch Lgo%=\n"                                                \
     ".p2align 8\n"                                                    \
     "insider_cdtab_" REG_STR(REG_KM) "_%c[who]:\n"                     \
@@ -231,48 +231,52 @@ struct RegState {
     "s_setpc_b64 s[" REG_PB ":" REG_PB "+1]\n"                        \
     "Lout%=:\n"                                                       \
     "s_waitcnt lgkmcnt(0)\n"
-#define REG_TAIL2                                                     \
+// (the stash values a tail needs — D, the sweep-start beta and what — are requested at the END of the previous tail, behind its
+// writes, into registers the blocks do not touch: a tail starts computing at once)
+#define REG_LDS2                                                      \
     "ds_read_b64 %[t0], %[la]\n"                                      \
     "ds_read_b64 %[t1], %[la] offset:512\n"                           \
-    "ds_read_b64 v[2:3], %[la] offset:1024\n"                          \
+    "ds_read_b64 %[t2], %[la] offset:1024\n"                          \
     "ds_read_b64 %[t3], %[la] offset:1536\n"                          \
     "ds_read_b64 %[t4], %[la] offset:2048\n"                          \
-    "ds_read_b64 v[4:5], %[la] offset:2560\n"                          \
+    "ds_read_b64 %[t5], %[la] offset:2560\n"
+#define REG_LDS1                                                      \
+    "ds_read_b64 %[t0], %[la]\n"                                      \
+    "ds_read_b64 %[t2], %[la] offset:1024\n"                          \
+    "ds_read_b64 %[t4], %[la] offset:2048\n"
+#define REG_TAIL2                                                     \
     REG_NEXT_LIST                                                     \
     "v_fma_f64 %[t0], %[b0], %[t0], -%[h0]\n"                         \
     "v_fma_f64 %[t1], %[b1], %[t1], -%[h1]\n"                         \
     "v_add_f64 %[t4], %[t0], %[t4]\n"                                 \
-    "v_add_f64 %[dn], %[b0], -v[2:3]\n"                                \
+    "v_add_f64 %[dn], %[b0], -%[t2]\n"                                \
     "v_add_f64 %[t4], %[t4], 1.0\n"                                   \
-    "v_add_f64 v[4:5], %[t1], v[4:5]\n"                                 \
-    "v_add_f64 v[2:3], |%[b0]|, -|v[2:3]|\n"                            \
+    "v_add_f64 %[t5], %[t1], %[t5]\n"                                 \
+    "v_add_f64 %[t2], |%[b0]|, -|%[t2]|\n"                            \
     "v_fma_f64 %[t4], %[dn], %[t4], 0\n"                              \
     "v_add_f64 %[dn], %[b1], -%[t3]\n"                                \
-    "v_add_f64 v[4:5], v[4:5], 1.0\n"                                   \
+    "v_add_f64 %[t5], %[t5], 1.0\n"                                   \
     "v_add_f64 %[t3], |%[b1]|, -|%[t3]|\n"                            \
-    "v_fmac_f64 %[t4], %[dn], v[4:5]\n"                                \
-    "v_add_f64 v[2:3], v[2:3], %[t3]\n"                                 \
+    "v_fmac_f64 %[t4], %[dn], %[t5]\n"                                \
+    "v_add_f64 %[t2], %[t2], %[t3]\n"                                 \
     "ds_write_b64 %[la], %[b0] offset:1024\n"                         \
     "ds_write_b64 %[la], %[b1] offset:1536\n"                         \
     "ds_write_b64 %[la], %[t0] offset:2048\n"                         \
     "ds_write_b64 %[la], %[t1] offset:2560\n"                         \
-    "v_add_f64 v[2:3], v[2:3], %[t4]\n"                                 \
-    REG_ROWSUM REG_LOOP_END
+    "v_add_f64 v[2:3], %[t2], %[t4]\n"                                \
+    REG_LDS2 REG_ROWSUM REG_LOOP_END
 #define REG_TAIL1                                                     \
-    "ds_read_b64 %[t0], %[la]\n"                                      \
-    "ds_read_b64 v[2:3], %[la] offset:1024\n"                          \
-    "ds_read_b64 v[4:5], %[la] offset:2048\n"                          \
     REG_NEXT_LIST                                                     \
     "v_fma_f64 %[t0], %[b0], %[t0], -%[h0]\n"                         \
-    "v_add_f64 v[4:5], %[t0], v[4:5]\n"                                 \
-    "v_add_f64 %[dn], %[b0], -v[2:3]\n"                                \
+    "v_add_f64 %[t4], %[t0], %[t4]\n"                                 \
+    "v_add_f64 %[dn], %[b0], -%[t2]\n"                                \
     "ds_write_b64 %[la], %[b0] offset:1024\n"                         \
     "ds_write_b64 %[la], %[t0] offset:2048\n"                         \
-    "v_add_f64 v[4:5], v[4:5], 1.0\n"                                   \
-    "v_add_f64 v[2:3], |%[b0]|, -|v[2:3]|\n"                            \
-    "v_fma_f64 v[4:5], %[dn], v[4:5], 0\n"                              \
-    "v_add_f64 v[2:3], v[2:3], v[4:5]\n"                                 \
-    REG_ROWSUM REG_LOOP_END
+    "v_add_f64 %[t4], %[t4], 1.0\n"                                   \
+    "v_add_f64 %[t2], |%[b0]|, -|%[t2]|\n"                            \
+    "v_fma_f64 %[t4], %[dn], %[t4], 0\n"                              \
+    "v_add_f64 v[2:3], %[t2], %[t4]\n"                                \
+    REG_LDS1 REG_ROWSUM REG_LOOP_END
 #define REG_EPILOGUE(NBLK) REG_ORG(NBLK) " s_waitcnt lgkmcnt(0)\n"   /* exit block */
 #define REG_S48_63 "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
 #define REG_S64_97 "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"
@@ -318,7 +322,8 @@ struct RegState {
 // the column-update kernel also carries the blocks of two steps.
 #define REG_LOOP_OUTS2                                                                                                     \
     [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), [aw] "+v"(accw), [dl] "=&{v[2:3]}"(dl), \
-        [rb] "=&{v[4:5]}"(rb), [dn] "=&v"(dn), [t0] "=&v"(t0), [t1] "=&v"(t1), [t3] "=&v"(t3), [t4] "=&v"(t4), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand), [sk] "=&s"(sk), [p1] "=&s"(p1),   \
+        [rb] "=&{v[4:5]}"(rb), [dn] "=&v"(dn), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4),      \
+        [t5] "=&v"(t5), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand), [sk] "=&s"(sk), [p1] "=&s"(p1),   \
         [p2] "=&s"(p2), [p3] "=&s"(p3)
 #define REG_LOOP_INS_TAIL                                                                                                  \
     [tb0] "s"(tb0), [lm] "s"(lm), [run] "s"(run), [las] "s"(la), [tol] "s"(tol), [stop] "s"(stop), [la] "v"(lds), [who] "i"(WHO)
@@ -330,7 +335,7 @@ struct RegState {
                                                int &sw, int stop, uint64_t run, double la, double tol, uint32_t lds,     \
                                                double &accw, double &dl, uint64_t &cand)                                 \
     {                                                                                                                    \
-        double dn, rb, t0, t1, t3, t4;                                                                                   \
+        double dn, rb, t0, t1, t2, t3, t4, t5;                                                                           \
         int sk, p1, p2, p3;                                                                                              \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
         if constexpr (WHO == 0)                                                                                          \
@@ -355,6 +360,7 @@ struct RegState {
     __device__ __forceinline__ void reg_sweeps(RegState<2> &, const double (&)[2][KMAX], const uint32_t *, int &, int &, int, \
                                                uint64_t, double, double, uint32_t, double &, double &, uint64_t &) {}
 #endif
+#define REG_LDS REG_LDS2
 #define REG_KM 18
 #define REG_PBN 60
 REG_DEFINE_SWEEP2(18)
@@ -442,18 +448,20 @@ template <int WHO>
 __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][32], const uint32_t *) {}
 #endif
 
+#undef REG_LDS
+#define REG_LDS REG_LDS1
 #define REG_KM 16
 #define REG_PBN 64
 #define REG_LOOP_OUTS1                                                                                                      \
     [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [aw] "+v"(accw), [dl] "=&{v[2:3]}"(dl), [rb] "=&{v[4:5]}"(rb), [dn] "=&v"(dn),  \
-        [t0] "=&v"(t0), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand),                                                  \
+        [t0] "=&v"(t0), [t2] "=&v"(t2), [t4] "=&v"(t4), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand),                  \
         [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3)
 template <int WHO>
 __device__ __forceinline__ void reg_sweeps(RegState<1> &S, const double (&G)[1][16], const uint32_t *tb0, int &off, int &sw, int stop,
                                            uint64_t run, double la, double tol, uint32_t lds, double &accw, double &dl, uint64_t &cand)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double dn, rb, t0;
+    double dn, rb, t0, t2, t4;
     int sk, p1, p2, p3;
     const uint64_t lm = 0x0001000100010001ull;
     if constexpr (WHO == 0)
