@@ -159,7 +159,7 @@ struct RegState {
 // ---- the sweep LOOP as one asm statement (round 5, K <= 30) -------------------------------------------------------------------
 // Not only the sweep but the per-sweep bookkeeping and the loop control are inside the statement: the common path of a sweep
 // never leaves it.  Layout:
-//     entry:   load the successor list of sweep `sw` (row `off` of the order table), touch the row after it; branch to Lgo
+//     entry:   load the successor list of sweep `sw` (row `off` of the order table) and the stash values; branch to Lgo
 //     Lc:      the table of code blocks (one step each; the two-step blocks live in their own section)
 //     exit block (index KMAX): the exact loss change of the sweep (the instructions the compiler made of the C++ that
 //              stood here until round 4, in its order: same roundings), ++sw, the NEXT sweep's list requested BEFORE the
@@ -173,20 +173,11 @@ struct RegState {
 // the halves of a 64-bit operand: its two temporaries are therefore pinned to v[2:3] / v[4:5].
 #define REG_AD "%[tb0], %[off] offset:"
 #define REG_ROWSTR REG_STR(INSIDER_ORDER_ROW)
-#ifndef INSIDER_REG_TOUCHES
-#define INSIDER_REG_TOUCHES 4
-#endif
-#if INSIDER_REG_TOUCHES == 4
-#define REG_TOUCH                                                     \
-    "s_load_dword %[sk], " REG_AD REG_ROWSTR "\n"                      \
-    "s_load_dword %[p1], " REG_AD REG_ROWSTR "+0x40\n"                 \
-    "s_load_dword %[p2], " REG_AD REG_ROWSTR "+0x80\n"                 \
-    "s_load_dword %[p3], " REG_AD REG_ROWSTR "+0xc0\n"
-#else
-#define REG_TOUCH
-#endif
+// (No look-ahead touches of the row after next: with the list requested a whole bookkeeping ahead they are not needed any more —
+// A/B in round 5: 0.6 % fewer sweep-kernel ms without them; in the per-sweep form of round 4, where the list load stood in front of
+// the sweep, they were worth 5 %.)
 #define REG_LOOP_ENTRY                                                \
-    REG_LDS REG_CAT(REG_LOADS_, REG_KM)(REG_AD) REG_TOUCH             \
+    REG_LDS REG_CAT(REG_LOADS_, REG_KM)(REG_AD)                       \
     "s_branch Lgo%=\n"                                                \
     ".p2align 8\n"                                                    \
     "insider_cdtab_" REG_STR(REG_KM) "_%c[who]:\n"                     \
@@ -217,7 +208,7 @@ struct RegState {
     "s_and_b32 %[off], %[sw], (" REG_STR(INSIDER_PERM_PERIOD) "-1)\n"  \
     "s_mulk_i32 %[off], " REG_ROWSTR "\n"                             \
     "s_waitcnt lgkmcnt(0)\n"                                          \
-    REG_CAT(REG_LOADS_, REG_KM)(REG_AD) REG_TOUCH
+    REG_CAT(REG_LOADS_, REG_KM)(REG_AD)
 #define REG_LOOP_END                                                  \
     "v_add_f64 %[aw], %[aw], |v[2:3]|\n"                              \
     "v_cmp_nlt_f64_e64 vcc, %[tol], |v[2:3]|\n"                       \
@@ -323,8 +314,7 @@ struct RegState {
 #define REG_LOOP_OUTS2                                                                                                     \
     [h0] "+v"(S.y[0]), [h1] "+v"(S.y[1]), [b0] "+v"(S.beta[0]), [b1] "+v"(S.beta[1]), [aw] "+v"(accw), [dl] "=&{v[2:3]}"(dl), \
         [rb] "=&{v[4:5]}"(rb), [dn] "=&v"(dn), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4),      \
-        [t5] "=&v"(t5), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand), [sk] "=&s"(sk), [p1] "=&s"(p1),   \
-        [p2] "=&s"(p2), [p3] "=&s"(p3)
+        [t5] "=&v"(t5), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand)
 #define REG_LOOP_INS_TAIL                                                                                                  \
     [tb0] "s"(tb0), [lm] "s"(lm), [run] "s"(run), [las] "s"(la), [tol] "s"(tol), [stop] "s"(stop), [la] "v"(lds), [who] "i"(WHO)
 #define REG_LOOP_CLOBBERS "vcc", REG_CLOBBERS
@@ -336,7 +326,6 @@ struct RegState {
                                                double &accw, double &dl, uint64_t &cand)                                 \
     {                                                                                                                    \
         double dn, rb, t0, t1, t2, t3, t4, t5;                                                                           \
-        int sk, p1, p2, p3;                                                                                              \
         const uint64_t lm = 0x0001000100010001ull;                                                                       \
         if constexpr (WHO == 0)                                                                                          \
             asm volatile(REG_LOOP_ENTRY REG_LIST_LO(REG_BLOCK2_LO) REG_HB_##KMAX(REG_HI16) REG_ORG(KMAX) REG_TAIL2            \
@@ -454,15 +443,13 @@ __device__ __forceinline__ void reg_sweep(RegState<2> &, const double (&)[2][32]
 #define REG_PBN 64
 #define REG_LOOP_OUTS1                                                                                                      \
     [h0] "+v"(S.y[0]), [b0] "+v"(S.beta[0]), [aw] "+v"(accw), [dl] "=&{v[2:3]}"(dl), [rb] "=&{v[4:5]}"(rb), [dn] "=&v"(dn),  \
-        [t0] "=&v"(t0), [t2] "=&v"(t2), [t4] "=&v"(t4), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand),                  \
-        [sk] "=&s"(sk), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3)
+        [t0] "=&v"(t0), [t2] "=&v"(t2), [t4] "=&v"(t4), [sw] "+s"(sw), [off] "+s"(off), [cand] "=&s"(cand)
 template <int WHO>
 __device__ __forceinline__ void reg_sweeps(RegState<1> &S, const double (&G)[1][16], const uint32_t *tb0, int &off, int &sw, int stop,
                                            uint64_t run, double la, double tol, uint32_t lds, double &accw, double &dl, uint64_t &cand)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     double dn, rb, t0, t2, t4;
-    int sk, p1, p2, p3;
     const uint64_t lm = 0x0001000100010001ull;
     if constexpr (WHO == 0)
         asm volatile(REG_LOOP_ENTRY REG_LIST_LO(REG_BLOCK1) REG_ORG(16) REG_TAIL1 REG_PAIRS_OPEN REG_LIST_LO(REGP1_ROW_LO) REG_PAIRS_CLOSE
