@@ -356,6 +356,223 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
     cf_store<NB, true>(acc, tr, a, j, lane, rtr, qh, ss);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_col_paircnt with the SECOND product (M += a_l p_l', 16 of its 22 matrix instructions per 16 levels at c3) on
+// v_mfma_f64_4x4x4, NB <= 2.  The 16x16x4 form sustains ~0.6 of the f64 matrix peak chip-wide, the 4x4x4 form ~0.9
+// (tools/ubench_mfma4.hip).  Operand map of the instruction (k_list_stats4): A[b][i][k] in lane 16 k + 4 b + i, B[b][k][j] in
+// lane 16 k + 4 b + j, D[b][i][j] in lane 16 i + 4 b + j, four independent blocks b.  With lane = (g4, c16 = 4 b + i):
+//  * P as the count product leaves it (register s of lane (g4, c16) = level 4 s + g4, column c16) IS a B operand: k = g4, block b
+//    owns columns 4 b .. 4 b + 3 of the 16;
+//  * a factor-row register in the natural layout (lane (g4, c16) = level 4 s + g4, component c16) IS an A operand whose block b
+//    owns components 4 b .. 4 b + 3: the instruction gives the four DIAGONAL 4 x 4 tiles of a 16 x 16 block.  The other twelve come
+//    from the same rows read at component (c16 + 4 x) mod 16, x = 1 .. 3: block b then owns row tile (b + x) mod 4 — sixteen
+//    instructions cover the 64 tiles of a 32 x 32 product once (a Latin square), and the rotated operands cost no vector
+//    instruction: the factor rows (identical for every gene) are staged once per block in LDS, four levels x 16 components
+//    contiguous, and each lane reads its four rotations from there.  (Rotating P instead is 12 v_mov_dpp per four levels on
+//    the port the f64 matrix instructions hold.)
+// acc[bi][bj][x] of lane (g4, b, j) = M[16 bi + 4 ((b + x) & 3) + g4][16 bj + 4 b + j].
+// LDS: per wave two 16 x 17 tiles | R'R | table rows | factor rows [position][level / 4][bi][level % 4][16]
+template <int NB, int WPB, bool ZC = false>
+__global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngroups)
+{
+    static_assert(NB <= 2, "accumulators of the 4x4x4 form");
+    constexpr int KP = Geo<NB>::KP;
+    extern __shared__ double s_c4[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    double *tr = s_c4 + (size_t)w * 16 * 17;
+    double *rtr = s_c4 + (size_t)WPB * 16 * 17;
+    double *tabs = rtr + KP * KP;
+    double *rows = tabs + 4 * a.nsteps * KP;
+    const int npos = a.c + (ZC ? 1 : 0);
+    for (int i = threadIdx.x; i < KP * KP; i += WPB * 64) rtr[i] = (i / KP < a.K && i % KP < a.K) ? a.RtR[i] : 0.0;
+    for (int i = threadIdx.x; i < 4 * a.nsteps * KP; i += WPB * 64) {
+        const int r = i / KP, k = i % KP;
+        const int q = r < a.tab_skip_lo ? r : r + a.tab_skip_n;
+        tabs[i] = r < a.tab_rows ? a.Astack[(size_t)q * KP + k] : 0.0;
+    }
+    {
+        int pb4 = 0;   // quads of levels in front of position t
+        for (int t = 0; t < npos; ++t) {
+            const int nq = (a.L[t] + 3) >> 2;
+            const double *At = a.Astack + (size_t)a.off[t] * KP;   // rows beyond the last level: the next covariate's or the zero padding
+            for (int i = threadIdx.x; i < 4 * nq * KP; i += WPB * 64) {
+                const int l = i / KP, k = i % KP;
+                rows[((size_t)(pb4 + (l >> 2)) * NB + (k >> 4)) * 64 + (l & 3) * 16 + (k & 15)] = At[i];
+            }
+            pb4 += nq;
+        }
+        for (int i = threadIdx.x; i < 4 * KP; i += WPB * 64) rows[(size_t)pb4 * NB * 64 + i] = 0.0;   // the quad the look-ahead reads past the end
+    }
+    __syncthreads();
+    const int g4 = lane >> 4, c16 = lane & 15;
+    const int bpl = a.nsteps <= 4 ? 4 : 8;
+    double tb[CP_MAXSTEPS][NB];
+#pragma unroll
+    for (int s = 0; s < CP_MAXSTEPS; ++s)
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) tb[s][bb] = s < a.nsteps ? tabs[(4 * s + g4) * KP + 16 * bb + c16] : 0.0;
+    double tbz[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) tbz[bb] = ZC ? a.Astack[(size_t)(a.SLcat + g4) * KP + 16 * bb + c16] : 0.0;
+    const unsigned off_c = (unsigned)lane * (unsigned)bpl, off_h = (unsigned)g4 * 4u;
+    // this lane's four rotations inside a quad of levels (doubles)
+    const double *rl[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) rl[x] = rows + g4 * 16 + ((c16 + 4 * x) & 15);
+    struct Blk {
+        uint32_t cw[2];
+        float4 hn;
+        double z;
+    };
+    // a block keeps its staged rows for every group of WPB genes it takes (grid = the resident blocks: the staging is paid once)
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    int j = grp * WPB + w;        // wave-uniform
+    if (a.list) {
+        if (j >= *a.list_count) break;
+        j = a.list[j];
+    } else {
+        if (j >= a.p) break;
+        if (a.skip_bkt && (int)a.skip_bkt[j] <= *a.skip_last) continue;
+    }
+    double qh[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) qh[bb] = a.Qheld[(size_t)j * KP + 16 * bb + c16];
+    const double ss = a.yy_all[j] - a.yy_train[j];
+    double acc[NB][NB][4];
+#pragma unroll
+    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[bi][bj][x] = 0.0;
+    const uint8_t *cj = a.cnt + (size_t)j * a.cnt_stride;
+    const float *hj = a.hn + (size_t)j * a.hn_stride;
+    const double *zj = ZC ? a.zt + (size_t)j * a.zt_stride : nullptr;
+    int pb4 = 0;
+    for (int t = 0; t < npos; ++t) {
+        const int Lo = a.L[t];
+        const bool cross = a.nlater[t] > 0;   // wave-uniform
+        const uint8_t *ct = cj + a.cnt_off[t];
+        const float *ht = hj + a.hn_off[t];
+        const double *zt = ZC ? zj + a.zt_off[t] : nullptr;
+        auto fetch = [&](int l0, Blk &b) {
+            if constexpr (ZC) b.z = zt[(size_t)(l0 >> 4) * 64 + lane];
+            b.cw[0] = b.cw[1] = 0;
+            if (cross) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(ct + (size_t)(l0 >> 4) * 64 * bpl + off_c);
+                b.cw[0] = src[0];
+                if (bpl == 8) b.cw[1] = src[1];
+            }
+            b.hn = *reinterpret_cast<const float4 *>(ht + l0 + off_h);
+        };
+        // the four rotations of the factor rows of quad qd (levels 4 qd .. 4 qd + 3 of this position); qd may be one past the end
+        auto rows_of = [&](int qd, double (&av)[4][NB]) {
+            const size_t q0 = (size_t)(pb4 + qd) * NB * 64;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int bi = 0; bi < NB; ++bi) av[x][bi] = rl[x][q0 + (size_t)bi * 64];
+        };
+        auto step = [&](const double (&av)[4][NB], double hn, const d4 (&P)[NB], int s) {
+            double pr[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) pr[bb] = fma(hn, av[0][bb], P[bb][s]);
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < NB; ++bj)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        acc[bi][bj][x] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[x][bi], pr[bj], acc[bi][bj][x], 0, 0, 0);
+        };
+        double avA[4][NB], avB[4][NB];   // the rows of the current quad and of the next one (in flight during the current one's products)
+        auto compute = [&](int l0, const Blk &cur) {
+            d4 P[NB];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) P[bb] = d4{0.0, 0.0, 0.0, 0.0};
+            if (cross) {
+#pragma unroll
+                for (int s = 0; s < CP_MAXSTEPS; ++s)
+                    if (s < a.nsteps) {   // wave-uniform
+                        const double cv = (double)((cur.cw[s >> 2] >> (8 * (s & 3))) & 0xffu);
+#pragma unroll
+                        for (int bb = 0; bb < NB; ++bb)
+                            P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv, tb[s][bb], P[bb], 0, 0, 0);
+                    }
+            }
+            if constexpr (ZC) {
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.z, tbz[bb], P[bb], 0, 0, 0);
+            }
+            const int qd = l0 >> 2;
+            rows_of(qd + 1, avB);
+            __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
+            step(avA, (double)cur.hn.x, P, 0);
+            if (l0 + 4 < Lo) {   // wave-uniform
+                rows_of(qd + 2, avA);
+            __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
+                step(avB, (double)cur.hn.y, P, 1);
+                if (l0 + 8 < Lo) {
+                    rows_of(qd + 3, avB);
+            __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
+                    step(avA, (double)cur.hn.z, P, 2);
+                    if (l0 + 12 < Lo) {
+                        rows_of(qd + 4, avA);
+            __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
+                        step(avB, (double)cur.hn.w, P, 3);
+                    }
+                }
+            }
+        };
+        Blk b0, b1;
+        fetch(0, b0);
+        rows_of(0, avA);
+        for (int l0 = 0; l0 < Lo; l0 += 32) {
+            if (l0 + 16 < Lo) fetch(l0 + 16, b1);
+            compute(l0, b0);
+            if (l0 + 16 < Lo) {
+                if (l0 + 32 < Lo) fetch(l0 + 32, b0);
+                compute(l0 + 16, b1);
+            }
+        }
+        pb4 += (Lo + 3) >> 2;
+    }
+    // epilogue: Gc = M + M' block by block through one 16 x 17 tile; the record as cf_store writes it
+    {
+        const int b = c16 >> 2, jj = c16 & 3;
+        double *out = a.stat + (size_t)j * Geo<NB>::STAT;
+        int blk = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj, ++blk) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) tr[(4 * ((b + x) & 3) + g4) * 17 + 4 * b + jj] = acc[bi][bj][x];
+                wave_sync();
+                d4 res;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res[r] = tr[(g4 + 4 * r) * 17 + c16];
+                wave_sync();
+#pragma unroll
+                for (int x = 0; x < 4; ++x) tr[(4 * ((b + x) & 3) + g4) * 17 + 4 * b + jj] = acc[bj][bi][x];
+                wave_sync();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ra = 16 * bi + g4 + 4 * r, cb = 16 * bj + c16;
+                    res[r] = rtr[ra * KP + cb] - (res[r] + tr[c16 * 17 + g4 + 4 * r]);
+                }
+                wave_sync();
+                if (bi == NB - 1 && g4 == 3) {
+                    const int col = 16 * bj + c16;
+                    res[3] = col < a.K ? qh[bj] : (col == KP - 1 ? ss : 0.0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[blk * 256 + (g4 + 4 * r) * 16 + c16] = res[r];
+            }
+    }
+    }
+}
+
 // The real-valued count table of the continuous covariates (ColFacArgs::zt) and the held-out sums sum_{i in H(j)} x_ij z_ik,
 // once per data set.  One wave per gene; every sum runs over the gene's held-out list in list order (fixed order:
 // reproducible), each lane owning the levels l = lane, lane + 64, ... of a position.  lev: [c][n] zero-based levels; Zc: [m][n].

@@ -187,6 +187,7 @@ struct insider_hip_handle {
     // order table holds absolute block addresses (insider_cd_reg.hpp), published by a probe launch of that kernel
     unsigned long long cd_code_base = 0, cd_pair_base = 0;
     unsigned long long *code_base_dev = nullptr;   // where the probe launch stores them (workspace)
+    int col_mfma4 = 0;                 // option "col_mfma4": pair-count statistics with the second product on v_mfma_f64_4x4x4 (k_col_paircnt4)
     int cd_pairs = 1;                  // option "cd_pairs": route the sweeps through the kernel's blocks of two coordinate steps (default)
     uint8_t *order = nullptr;          // the sweep-order table the next column solve reads: one of order_buf
     uint8_t *order_buf[2] = {nullptr, nullptr};   // two tables: the next outer iteration's is built while the current solve runs
@@ -711,6 +712,27 @@ bool use_col_factored(const insider_hip_handle *h) { return col_stats_path(h) !=
 // the pair-count statistics kernel (insider_col_factored.hpp) on `blocks` blocks of four genes
 int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipStream_t st)
 {
+    if (h->col_mfma4 && h->NB <= 2) {
+        // second product on the 4x4x4 matrix instruction, factor rows of every position staged in LDS (k_col_paircnt4);
+        // option value 2: one block per group of four genes
+        size_t quads = 1;
+        for (int t = 0; t < a.c + (a.zt ? 1 : 0); ++t) quads += (size_t)(a.L[t] + 3) / 4;
+        const size_t lds = ((size_t)4 * 16 * 17 + (size_t)h->KP * h->KP + (size_t)4 * a.nsteps * h->KP + 4 * quads * h->KP) * sizeof(double);
+        if (lds <= 64 * 1024) {
+            // as many blocks as stay resident (48.6 KB of LDS at c3: three per CU); each walks the groups of four genes with the grid's stride
+            const int resident = std::max(1, std::min((int)(160 * 1024 / lds), a.zt ? 2 : 3)) * std::max(1, h->n_simd / 4);   // registers: 162 (180 with real-valued counts)
+            const int nb = std::min(blocks, h->col_mfma4 >= 2 ? blocks : resident);
+            if (h->NB == 1) {
+                if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<1, 4, true>), dim3(nb), dim3(256), lds, st, a, blocks);
+                else hipLaunchKernelGGL((k_col_paircnt4<1, 4, false>), dim3(nb), dim3(256), lds, st, a, blocks);
+            } else {
+                if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<2, 4, true>), dim3(nb), dim3(256), lds, st, a, blocks);
+                else hipLaunchKernelGGL((k_col_paircnt4<2, 4, false>), dim3(nb), dim3(256), lds, st, a, blocks);
+            }
+            KCHECK();
+            return INSIDER_OK;
+        }
+    }
     NB_DISPATCH(h->NB, {
         (void)WPB_;
         const size_t lds = ((size_t)4 * 16 * 17 + (size_t)Geo<NB_>::KP * Geo<NB_>::KP + (size_t)4 * a.nsteps * Geo<NB_>::KP) * sizeof(double);
@@ -2187,6 +2209,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
     else if (s == "list_fine") h->list_fine = (int)value;       // 1 (default) = per-entry statistics on v_mfma_f64_4x4x4 for 16 <= K <= 31, 0 = on 16x16x4
+    else if (s == "col_mfma4") h->col_mfma4 = (int)value;         // 1 = k_col_paircnt4 (K <= 31, factor rows fit LDS), 0 = k_col_paircnt
     else if (s == "cd_pairs") h->cd_pairs = (int)value;           // 1 (default) = sweeps routed through the blocks of two coordinate steps (K <= 30; same iterates), 0 = one step per block
     else if (s == "cd_split") h->cd_split = (int)value;           // 2 = steady-state column steps run split (long genes first, on their own stream); 0 (default) = never (measured: no gain, see use_split)
     else if (s == "cd_long_frac") h->cd_long_frac = value;        // at most this fraction of the genes counts as long (default 0.03)

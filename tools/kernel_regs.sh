@@ -1,20 +1,21 @@
 #!/bin/bash
-# VGPR / SGPR / scratch use of the kernels matching $1 (default: the register-resident sweep kernels) in the shipped library
-R=$(dirname $(dirname $(readlink -f $0)))
-T=$(mktemp -d); cp ${LIB:-$R/insider_amd/libinsider_hip.so} $T/lib.so; cd $T
-/opt/rocm/lib/llvm/bin/llvm-objdump --offloading lib.so > /dev/null
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes lib.so.0.hipv4-amdgcn-amd-amdhsa--gfx950 | python3 -c "
-import sys,re
-pat=sys.argv[1]
-cur={}
-for line in sys.stdin:
-    m=re.match(r'\s*-?\s*\.(\w+):\s*(.*)',line)
-    if not m: continue
-    k,v=m.group(1),m.group(2).strip()
-    if k=='agpr_count' and cur.get('name'): pass
-    cur[k]=v
-    if k=='wavefront_size':
-        if re.search(pat,cur.get('name','')): print(cur.get('name'), 'vgpr',cur.get('vgpr_count'),'sgpr',cur.get('sgpr_count'),'scratch',cur.get('private_segment_fixed_size'),'vgpr_spills',cur.get('vgpr_spill_count'),'sgpr_spills',cur.get('sgpr_spill_count'),'lds',cur.get('group_segment_fixed_size'))
-        cur={}
-" "${1:-k_cd_(cols|batch)_reg}"
-rm -rf $T
+# registers / scratch of the kernels of the built library whose (mangled) name matches $1; $2 = directory for the extracted code
+# object and its disassembly (default: a fresh one under /tmp)
+PAT=${1:-k_}
+D=${2:-$(mktemp -d /tmp/co.XXXX)}
+R=$(cd "$(dirname "$0")/.." && pwd)
+cp $R/insider_amd/libinsider_hip.so $D/ && cd $D || exit 1
+/opt/rocm/lib/llvm/bin/llvm-objdump --offloading libinsider_hip.so > /dev/null
+CO=$(ls | grep gfx950 | head -1)
+/opt/rocm/lib/llvm/bin/llvm-readelf --notes $CO > notes.txt
+/opt/rocm/lib/llvm/bin/llvm-objdump -d $CO > dis.txt
+python3 - "$PAT" <<'PY'
+import sys, re
+t = open('notes.txt').read()
+for blk in t.split('- .agpr_count')[1:]:
+    name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+    if sys.argv[1] in name:
+        g = lambda k: re.search(r'\.%s:\s+(\d+)' % k, blk).group(1)
+        print(name, 'vgpr', g('vgpr_count'), 'sgpr', g('sgpr_count'), 'spill', g('vgpr_spill_count'), 'scratch', g('private_segment_fixed_size'))
+PY
+echo $D

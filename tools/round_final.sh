@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round-4 closing job (one gpurun call, AFTER profiles/traffic.json and profiles/issue.json were re-taken on the final library):
-# the bench lines that carry the PMC figures, the whole GPU test suite, randomised parity sweeps.  Outputs under gpurun_out/r04.
+# Closing job of a round (one gpurun call, AFTER profiles/traffic.json and profiles/issue.json were re-taken on the final library; tools/round_final.sh r05):
+# the bench lines that carry the PMC figures, the whole GPU test suite, randomised parity sweeps.  Outputs under gpurun_out/<round>.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/r04
+TAG=${1:-r05}
+OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 python3 -c "import __graft_entry__ as g; g.build()" || exit 1
