@@ -136,7 +136,9 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * "list_fine" (1, default = the per-entry statistics kernel uses the 4x4x4 form of the f64 matrix instruction for 16 <= K <= 31
  * [fewer wasted outputs than 16 x 16 blocks], 0 = the 16x16x4 form; same sums in another order), "row_gemm" / "row_gemm_waves" (1, default = the per-level weighted Gram sums of a covariate with >= 49
  * levels come from one GEMM over genes, cut into row_gemm_waves [1024] waves; 0 = one weighted rank-one update per (level, gene);
- * same sums in another order, results agree to rounding), "cd_pairs" (1, default = the register-resident sweep kernel [K <= 30] is routed through its blocks of TWO
+ * same sums in another order, results agree to rounding), "col_mfma4" (1, default = the pair-count column statistics [K <= 31, the
+ * factor rows of all covariates within 64 KB of LDS] form sum_l a_l p_l' on the 4x4x4 form of the f64 matrix instruction, rows read
+ * in four rotations from LDS, resident blocks walking the genes; 0 = the 16x16x4 form; same sums to rounding), "cd_pairs" (1, default = the register-resident sweep kernel [K <= 30] is routed through its blocks of TWO
  * coordinate steps wherever two consecutive coordinates of a sweep's order share a coordinate slot: a third fewer computed jumps,
  * the same steps in the same order — bit-identical iterates; 0 = one step per block), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
  * cd_cold_iters outer iterations of a call [default 3]: the register-resident sweep kernel stops at sweep cd_pass1 [64; 0 = one

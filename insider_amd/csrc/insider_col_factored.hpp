@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
 //    the port the f64 matrix instructions hold.)
 // acc[bi][bj][x] of lane (g4, b, j) = M[16 bi + 4 ((b + x) & 3) + g4][16 bj + 4 b + j].
 // LDS: per wave two 16 x 17 tiles | R'R | table rows | factor rows [position][level / 4][bi][level % 4][16]
-template <int NB, int WPB, bool ZC = false>
+template <int NB, int WPB, int MAXS, bool ZC = false>
 __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngroups)
 {
     static_assert(NB <= 2, "accumulators of the 4x4x4 form");
@@ -405,10 +405,10 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngr
     }
     __syncthreads();
     const int g4 = lane >> 4, c16 = lane & 15;
-    const int bpl = a.nsteps <= 4 ? 4 : 8;
-    double tb[CP_MAXSTEPS][NB];
+    constexpr int bpl = MAXS <= 4 ? 4 : 8;   // count bytes per lane and block
+    double tb[MAXS][NB];             // MAXS = 4 or 8 >= nsteps: the table operand costs 2 NB registers per k-step
 #pragma unroll
-    for (int s = 0; s < CP_MAXSTEPS; ++s)
+    for (int s = 0; s < MAXS; ++s)
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) tb[s][bb] = s < a.nsteps ? tabs[(4 * s + g4) * KP + 16 * bb + c16] : 0.0;
     double tbz[NB];
@@ -465,13 +465,16 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngr
             }
             b.hn = *reinterpret_cast<const float4 *>(ht + l0 + off_h);
         };
-        // the four rotations of the factor rows of quad qd (levels 4 qd .. 4 qd + 3 of this position); qd may be one past the end
-        auto rows_of = [&](int qd, double (&av)[4][NB]) {
-            const size_t q0 = (size_t)(pb4 + qd) * NB * 64;
+        // the four rotations of the factor rows of quad s (0 .. 4: 4 = the next block's first) of the block of 16 levels at rp:
+        // constant offsets from four addresses that move once per block
+        const double *rp[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) rp[x] = rl[x] + (size_t)pb4 * NB * 64;
+        auto rows_of = [&](int s, double (&av)[4][NB]) {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int bi = 0; bi < NB; ++bi) av[x][bi] = rl[x][q0 + (size_t)bi * 64];
+                for (int bi = 0; bi < NB; ++bi) av[x][bi] = rp[x][(s * NB + bi) * 64];
         };
         auto step = [&](const double (&av)[4][NB], double hn, const d4 (&P)[NB], int s) {
             double pr[NB];
@@ -492,7 +495,7 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngr
             for (int bb = 0; bb < NB; ++bb) P[bb] = d4{0.0, 0.0, 0.0, 0.0};
             if (cross) {
 #pragma unroll
-                for (int s = 0; s < CP_MAXSTEPS; ++s)
+                for (int s = 0; s < MAXS; ++s)
                     if (s < a.nsteps) {   // wave-uniform
                         const double cv = (double)((cur.cw[s >> 2] >> (8 * (s & 3))) & 0xffu);
 #pragma unroll
@@ -504,25 +507,26 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngr
 #pragma unroll
                 for (int bb = 0; bb < NB; ++bb) P[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.z, tbz[bb], P[bb], 0, 0, 0);
             }
-            const int qd = l0 >> 2;
-            rows_of(qd + 1, avB);
+            rows_of(1, avB);
             __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
             step(avA, (double)cur.hn.x, P, 0);
             if (l0 + 4 < Lo) {   // wave-uniform
-                rows_of(qd + 2, avA);
+                rows_of(2, avA);
             __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
                 step(avB, (double)cur.hn.y, P, 1);
                 if (l0 + 8 < Lo) {
-                    rows_of(qd + 3, avB);
+                    rows_of(3, avB);
             __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
                     step(avA, (double)cur.hn.z, P, 2);
                     if (l0 + 12 < Lo) {
-                        rows_of(qd + 4, avA);
+                        rows_of(4, avA);
             __builtin_amdgcn_sched_barrier(0);   // the look-ahead reads stay in front of the products they hide behind
                         step(avB, (double)cur.hn.w, P, 3);
                     }
                 }
             }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) rp[x] += 4 * NB * 64;
         };
         Blk b0, b1;
         fetch(0, b0);

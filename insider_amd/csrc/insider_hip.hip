@@ -187,7 +187,8 @@ struct insider_hip_handle {
     // order table holds absolute block addresses (insider_cd_reg.hpp), published by a probe launch of that kernel
     unsigned long long cd_code_base = 0, cd_pair_base = 0;
     unsigned long long *code_base_dev = nullptr;   // where the probe launch stores them (workspace)
-    int col_mfma4 = 0;                 // option "col_mfma4": pair-count statistics with the second product on v_mfma_f64_4x4x4 (k_col_paircnt4)
+    int mm_fast = 1;                   // option "mm_fast": the small dense products on k_mm_rows2 / k_mm_reduce2 (default; 2: two column tiles per wave in the reductions)
+    int col_mfma4 = 1;                 // option "col_mfma4": pair-count statistics with the second product on v_mfma_f64_4x4x4 (k_col_paircnt4; default)
     int cd_pairs = 1;                  // option "cd_pairs": route the sweeps through the kernel's blocks of two coordinate steps (default)
     uint8_t *order = nullptr;          // the sweep-order table the next column solve reads: one of order_buf
     uint8_t *order_buf[2] = {nullptr, nullptr};   // two tables: the next outer iteration's is built while the current solve runs
@@ -476,11 +477,25 @@ int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *
 }
 
 // ---- the small dense products on MFMA (insider_mm.hpp) -------------------------------------------------------------------
+// k_mm_rows2: tiles of 16 rows one wave takes — one until the grid fills every SIMD twice, then as many as keep it at that
+int mm_tiles_per_wave(const insider_hip_handle *h, int tiles) { return std::max(1, tiles / (2 * h->n_simd)); }
+
 // out[M x KP] = X[M x Kd] W[Kd x KP]   (W row-major with pitch KP)
 int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M, int Kd, const double *W, double *out,
                       hipStream_t st = nullptr)
 {
     if (!st) st = h->stream;
+    const size_t lds2 = (size_t)4 * cdiv(Kd, 16) * h->NB * 64 * sizeof(double);   // k_mm_rows2: W staged in LDS
+    if (h->mm_fast && ldx % 2 == 0 && lds2 <= 64 * 1024) {
+        const int tiles = cdiv(M, 16), tpw = mm_tiles_per_wave(h, tiles);
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            hipLaunchKernelGGL((k_mm_rows2<NB_, false>), dim3(cdiv(cdiv(tiles, tpw), 4), 1), dim3(256), lds2, st, X, ldx, M, Kd, W,
+                               h->KP, h->KP, out, (int64_t)h->KP, h->KP, tpw);
+        });
+        KCHECK();
+        return INSIDER_OK;
+    }
     NB_DISPATCH(h->NB, {
         (void)WPB_;
         hipLaunchKernelGGL((k_mm_rows<NB_, false>), dim3(cdiv(cdiv(M, 16), 4), 1), dim3(256), 0, st, X, ldx, M, Kd, W,
@@ -498,6 +513,18 @@ int launch_mm_reduce_kp(insider_hip_handle *h, const double *X, int64_t ldx, con
     if (!st) st = h->stream;
     const int slabs = cdiv(M, MM_SLAB);
     if (nslab) *nslab = slabs;
+    if (h->mm_fast && L > 16) {   // several column tiles of X per wave, deeper look-ahead; the same partial sums (k_mm_reduce2)
+        const int lt = cdiv(L, 16);
+#define MR2(NBV, LTV)                                                                                                         \
+    hipLaunchKernelGGL((k_mm_reduce2<NBV, LTV>), dim3(slabs, cdiv(lt, LTV)), dim3(64), 0, st, X, ldx, Y, (int64_t)h->KP, M,   \
+                       MM_SLAB, L, h->KP, part, h->KP)
+        NB_DISPATCH(h->NB, {
+            (void)WPB_;
+            if (lt <= 2 || h->mm_fast == 2 || NB_ > 2) MR2(NB_, 2);
+            else MR2(NB_, 4);
+        });
+#undef MR2
+    } else
     NB_DISPATCH(h->NB, {
         (void)WPB_;
         hipLaunchKernelGGL((k_mm_reduce<NB_>), dim3(slabs, cdiv(L, 16)), dim3(64), 0, st, X, ldx, Y, (int64_t)h->KP, M,
@@ -712,7 +739,7 @@ bool use_col_factored(const insider_hip_handle *h) { return col_stats_path(h) !=
 // the pair-count statistics kernel (insider_col_factored.hpp) on `blocks` blocks of four genes
 int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipStream_t st)
 {
-    if (h->col_mfma4 && h->NB <= 2) {
+    if (h->col_mfma4 && h->NB <= 2 && !(a.zt && a.nsteps > 4)) {   // (real-valued counts with more than four k-steps: 180 registers, two waves per SIMD)
         // second product on the 4x4x4 matrix instruction, factor rows of every position staged in LDS (k_col_paircnt4);
         // option value 2: one block per group of four genes
         size_t quads = 1;
@@ -720,15 +747,18 @@ int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipSt
         const size_t lds = ((size_t)4 * 16 * 17 + (size_t)h->KP * h->KP + (size_t)4 * a.nsteps * h->KP + 4 * quads * h->KP) * sizeof(double);
         if (lds <= 64 * 1024) {
             // as many blocks as stay resident (48.6 KB of LDS at c3: three per CU); each walks the groups of four genes with the grid's stride
-            const int resident = std::max(1, std::min((int)(160 * 1024 / lds), a.zt ? 2 : 3)) * std::max(1, h->n_simd / 4);   // registers: 162 (180 with real-valued counts)
+            const int resident = std::max(1, std::min((int)(160 * 1024 / lds), (a.zt && a.nsteps > 4) ? 2 : 3)) * std::max(1, h->n_simd / 4);   // registers: 148 - 166 (180 with real-valued counts and more than four k-steps)
             const int nb = std::min(blocks, h->col_mfma4 >= 2 ? blocks : resident);
-            if (h->NB == 1) {
-                if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<1, 4, true>), dim3(nb), dim3(256), lds, st, a, blocks);
-                else hipLaunchKernelGGL((k_col_paircnt4<1, 4, false>), dim3(nb), dim3(256), lds, st, a, blocks);
-            } else {
-                if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<2, 4, true>), dim3(nb), dim3(256), lds, st, a, blocks);
-                else hipLaunchKernelGGL((k_col_paircnt4<2, 4, false>), dim3(nb), dim3(256), lds, st, a, blocks);
-            }
+#define PC4(NBV, MS)                                                                                                         \
+    {                                                                                                                        \
+        if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, true>), dim3(nb), dim3(256), lds, st, a, blocks);           \
+        else hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, false>), dim3(nb), dim3(256), lds, st, a, blocks);               \
+    }
+            if (h->NB == 1 && a.nsteps <= 4) PC4(1, 4)
+            else if (h->NB == 1) PC4(1, 8)
+            else if (a.nsteps <= 4) PC4(2, 4)
+            else PC4(2, 8)
+#undef PC4
             KCHECK();
             return INSIDER_OK;
         }
@@ -1107,6 +1137,20 @@ int launch_gene_v(insider_hip_handle *h, int q_begin, int q_end)
     // V[:, q_begin:q_end) = C A[q_begin:q_end, :]'  (A given "transposed": one row per output column)
     const int N = q_end - q_begin;
     if (N <= 0) return INSIDER_OK;
+    if (h->mm_fast) {   // A' staged in LDS once per block, C read in 16-byte pieces (k_mm_rows2)
+        const int tiles = cdiv((int)h->p, 16), tpw = mm_tiles_per_wave(h, tiles);
+        const size_t ldsb = (size_t)4 * cdiv(h->K, 16) * 64 * sizeof(double);
+#define GV2_LAUNCH(NT_)                                                                                                       \
+    hipLaunchKernelGGL((k_mm_rows2<NT_, true>), dim3(cdiv(cdiv(tiles, tpw), 4), cdiv(N, 16 * NT_)), dim3(256), ldsb * NT_, h->stream, \
+                       (const double *)h->C, (int64_t)h->KP, (int)h->p, h->K,                                                \
+                       (const double *)(h->Astack + (size_t)q_begin * h->KP), h->KP, N, h->Vlev + q_begin, (int64_t)h->SLP, N, tpw)
+        if (N <= 16) GV2_LAUNCH(1);
+        else if (N <= 32) GV2_LAUNCH(2);
+        else GV2_LAUNCH(4);
+#undef GV2_LAUNCH
+        KCHECK();
+        return INSIDER_OK;
+    }
 #define GV_LAUNCH(NT_)                                                                                                        \
     hipLaunchKernelGGL((k_mm_rows<NT_, true>), dim3(cdiv(cdiv((int)h->p, 16), 4), cdiv(N, 16 * NT_)), dim3(256), 0, h->stream, \
                        (const double *)h->C, (int64_t)h->KP, (int)h->p, h->K,                                                \
@@ -2209,6 +2253,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
     else if (s == "list_fine") h->list_fine = (int)value;       // 1 (default) = per-entry statistics on v_mfma_f64_4x4x4 for 16 <= K <= 31, 0 = on 16x16x4
+    else if (s == "mm_fast") h->mm_fast = (int)value;             // 0 = k_mm_rows / k_mm_reduce as in round 4
     else if (s == "col_mfma4") h->col_mfma4 = (int)value;         // 1 = k_col_paircnt4 (K <= 31, factor rows fit LDS), 0 = k_col_paircnt
     else if (s == "cd_pairs") h->cd_pairs = (int)value;           // 1 (default) = sweeps routed through the blocks of two coordinate steps (K <= 30; same iterates), 0 = one step per block
     else if (s == "cd_split") h->cd_split = (int)value;           // 2 = steady-state column steps run split (long genes first, on their own stream); 0 (default) = never (measured: no gain, see use_split)

@@ -848,6 +848,43 @@ def test_optimize_row_lambda_zero_is_fit_interaction(oracle):
     assert relerr(got, ref) < 1e-9
 
 
+@pytest.mark.parametrize("kw,m", [(dict(level_counts=(100, 10), n=600, p=70, K=30, f=0.1), 0),     # c3's structure: 7 blocks of 16 levels
+                                  (dict(level_counts=(50, 5), n=400, p=66, K=20, f=0.1), 0),       # c2's
+                                  (dict(level_counts=(37, 9, 3), n=500, p=41, K=15, f=0.2), 0),    # one 16 x 16 block, three covariates
+                                  (dict(level_counts=(21,), n=200, p=30, K=31, f=0.2), 0),         # no later covariate: no count product
+                                  (dict(level_counts=(9, 8, 7, 6), n=700, p=37, K=9, f=0.2), 0),   # six k-steps, two count dwords per lane
+                                  (dict(level_counts=(64, 4), n=500, p=50, K=16, f=0.15, with_na=True), 2),   # continuous columns
+                                  (dict(level_counts=(3, 2), n=60, p=9, K=4, f=0.3), 1)],
+                         ids=["c3", "c2", "three-cov", "one-cov", "six-steps", "ctns2", "tiny-ctns1"])
+def test_pair_count_statistics_on_the_4x4x4_matrix_instruction(oracle, kw, m):
+    """k_col_paircnt4 (option col_mfma4 = 1, the default for K <= 31 when the factor rows of all covariates fit LDS): the second
+    product of the pair-count statistics on v_mfma_f64_4x4x4 with the rows read in four rotations from LDS, blocks that stay
+    resident and walk the genes.  Same fits as k_col_paircnt (col_mfma4 = 0) to rounding, both against the oracle; p is not a
+    multiple of four and smaller than the resident grid."""
+    w = workloads.small(seed=123, **kw)
+    rng = np.random.default_rng(5)
+    Z = np.asfortranarray(rng.standard_normal((w.n, m))) if m else None
+    U0 = [np.asfortranarray(rng.normal(0.0, 0.001, size=(m, w.K)))] if m else []
+    out = {}
+    for fine in (1, 0):
+        ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
+        for k, v in PATHS["pair"].items():
+            ds.set_option(k, v)
+        ds.set_option("col_mfma4", fine)
+        A, C = _cp(w)
+        out[fine] = ds.optimize(A + [u.copy(order="F") for u in U0], C, w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=10, seed=4,
+                                inc_continuous=1 if m else 0)
+        assert ds.profile()["col_pair"]
+        ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + U0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                          max_iter=10, seed=4, **(dict(ctns=Z) if m else {}))
+    for fine in (1, 0):
+        np.testing.assert_allclose(out[fine]["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-8, equal_nan=True)
+        assert relerr(out[fine]["column_factor"], ref["column_factor"]) < 1e-6
+    np.testing.assert_allclose(out[1]["traj"][:, 1:8], out[0]["traj"][:, 1:8], rtol=1e-11, equal_nan=True)
+    assert relerr(out[1]["column_factor"], out[0]["column_factor"]) < 1e-9
+
+
 @pytest.mark.parametrize("alpha,tuning", [(0.4, 1), (0.0, 1), (0.3, 0), (0.0, 0), (1.0, 1)])
 def test_optimize_col_operator(oracle, alpha, tuning):
     w = workloads.small(K=12, n=140, p=100, seed=43, with_na=True)
