@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt(ColFacArgs a)
 // acc[bi][bj][x] of lane (g4, b, j) = M[16 bi + 4 ((b + x) & 3) + g4][16 bj + 4 b + j].
 // LDS: per wave two 16 x 17 tiles | R'R | table rows | factor rows [position][level / 4][bi][level % 4][16]
 template <int NB, int WPB, int MAXS, bool ZC = false>
-__global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngroups)
+__global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int nitems, unsigned *__restrict__ ticket, unsigned ticket_base, int npart, int cap)
 {
     static_assert(NB <= 2, "accumulators of the 4x4x4 form");
     constexpr int KP = Geo<NB>::KP;
@@ -424,14 +424,30 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int ngr
         float4 hn;
         double z;
     };
-    // a block keeps its staged rows for every group of WPB genes it takes (grid = the resident blocks: the staging is paid once)
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    int j = grp * WPB + w;        // wave-uniform
+    // A block keeps its staged rows for every gene its waves take (grid = the blocks that can be resident: the staging is paid
+    // once).  Genes are dealt by TICKET: a static split would hand a block that starts late (another kernel holding its CU —
+    // Qfull's product, a second fit on the same device) a full share to work off alone (measured: 0.28 -> 0.40 ms with a 20 us
+    // product beside it).  One atomic per wave and gene, requested before the wave starts on its current gene.  Atomics on ONE
+    // address retire at one per ~7 ns on this part — 50000 of them are 0.35 ms, more than the kernel — so there are npart
+    // counters on lines of their own: block b draws from counter b % npart (late blocks are spread over all of them), whose
+    // ticket t stands for gene t * npart + (b % npart), t < cap = ceil(nitems / npart).  The counters only ever grow: every
+    // wave ends on exactly one ticket >= cap, the grid is a multiple of npart, so a launch takes cap + (waves per counter)
+    // tickets from each and the host knows the next launch's base without a reset.
+    const int part = blockIdx.x % npart;
+    unsigned *tk = ticket + 32 * part;
+    auto take = [&]() {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(tk, 1u);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)v) - ticket_base;
+    };
+    for (unsigned cur = take(), nxt; cur < (unsigned)cap; cur = nxt) {
+    nxt = take();
+    if ((int)cur * npart + part >= nitems) continue;
+    int j = (int)cur * npart + part;   // wave-uniform
     if (a.list) {
-        if (j >= *a.list_count) break;
+        if (j >= *a.list_count) continue;
         j = a.list[j];
     } else {
-        if (j >= a.p) break;
         if (a.skip_bkt && (int)a.skip_bkt[j] <= *a.skip_last) continue;
     }
     double qh[NB];

@@ -174,6 +174,7 @@ struct insider_hip_handle {
     int max_items = 0;
     bool merged = false;              // the merged masked row update is available (categorical covariates only)
     int row_merged = 1;               // option: use it
+    int row_gemm4 = 1;                // option "row_gemm4": k_wgemm4 (v_mfma_f64_4x4x4) instead of k_wgemm
     int row_gemm = 1;                 // option "row_gemm": weighted SYRK of a many-level covariate as one GEMM over genes (k_wgemm)
     double *wg_part = nullptr;        // its per-slab partial sums
     int wg_waves = 1024;              // option "row_gemm_waves": waves the GEMM is cut into (sets the number of gene slabs)
@@ -183,10 +184,13 @@ struct insider_hip_handle {
     int *sweeps = nullptr, *failflag = nullptr;
     int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sched_bucket)
     unsigned long long *sweep_total = nullptr;
+    unsigned *pc4_ticket = nullptr;     // k_col_paircnt4's gene tickets (main launch, long-gene launch): counters that only grow
+    unsigned pc4_base[2] = {0, 0};      // ... and the value each stands at when its next launch starts
     // where the register-resident sweep kernel of the current K keeps its table of code blocks (K <= 32; 0 = not asked yet): the
     // order table holds absolute block addresses (insider_cd_reg.hpp), published by a probe launch of that kernel
     unsigned long long cd_code_base = 0, cd_pair_base = 0;
     unsigned long long *code_base_dev = nullptr;   // where the probe launch stores them (workspace)
+    int join_lean = 0;                 // option "join_lean" (bits): 1 = ev_prep behind ev_w, 2 = ev_side_done behind ev_qfull (one stream join where two were), 4 = Qfull behind Qheld
     int mm_fast = 1;                   // option "mm_fast": the small dense products on k_mm_rows2 / k_mm_reduce2 (default; 2: two column tiles per wave in the reductions)
     int col_mfma4 = 1;                 // option "col_mfma4": pair-count statistics with the second product on v_mfma_f64_4x4x4 (k_col_paircnt4; default)
     int cd_pairs = 1;                  // option "cd_pairs": route the sweeps through the kernel's blocks of two coordinate steps (default)
@@ -251,6 +255,8 @@ namespace {
 // stream's kernels wrote must reach the other stream's kernels (device scope: every kernel boundary does that), not the host
 constexpr unsigned EV_SYNC = hipEventDisableTiming | hipEventDisableSystemFence;
 
+constexpr int PC4_PARTS = 16;        // ticket counters of k_col_paircnt4 per launch site
+constexpr int MM_FAST_MIN = 16384;   // rows from which k_mm_rows2 / k_mm_reduce2 run (below: the staging and the longer waves cost more than they save; c1: 5000 genes)
 constexpr int MM_SLAB = 128;  // rows per partial of the reduction products (insider_mm.hpp)
 
 // every K-dependent device buffer of a handle (ensure_workspace), as pointer slots
@@ -262,7 +268,7 @@ std::vector<void **> workspace_slots(insider_hip_handle *h)
     add(h->gram_part); add(h->sc_part); add(h->gram_part2); add(h->sc_part2); add(h->lvl_part); add(h->lvl_sum); add(h->lvl_zero); add(h->fperm); add(h->lvl_sum_all);
     add(h->U); add(h->Ylvl); add(h->wpart); add(h->Vlev); add(h->Qheld); add(h->eq); add(h->sse_train); add(h->sse_test); add(h->b2);
     add(h->b1); add(h->loss_buf); add(h->stage); add(h->wg_part); add(h->wg_pair); add(h->sweeps); add(h->sweep_key); add(h->failflag);
-    add(h->sweep_total); add(h->order_buf[0]); add(h->order_buf[1]); add(h->gene_perm); add(h->sched_cnt[0]); add(h->sched_cnt[1]);
+    add(h->sweep_total); add(h->pc4_ticket); add(h->order_buf[0]); add(h->order_buf[1]); add(h->gene_perm); add(h->sched_cnt[0]); add(h->sched_cnt[1]);
     add(h->sched_rank); add(h->sched_bkt); add(h->sched_long); add(h->cd_hsave); add(h->cd_isave); add(h->cd_pass_slot);
     add(h->cd_pass_perm[0]); add(h->cd_pass_perm[1]); add(h->cd_pass_cnt); add(h->code_base_dev);
     for (int e = 0; e < insider_hip_handle::EARLY; ++e) add(h->perm_early[e]);
@@ -403,6 +409,9 @@ int ensure_workspace(insider_hip_handle *h, int K)
     // [0] a system was singular, [1] ridge genes wait for the general route, [2] genes stopped by max_sweeps, [3] longest solve
     if ((rc = dmalloc(&h->failflag, 4))) return rc;
     if ((rc = dmalloc(&h->sweep_total, 256))) return rc;
+    if ((rc = dmalloc(&h->pc4_ticket, (size_t)2 * PC4_PARTS * 32))) return rc;   // (a 128-byte line per counter)
+    HIPCHECK(hipMemsetAsync(h->pc4_ticket, 0, (size_t)2 * PC4_PARTS * 32 * sizeof(unsigned), h->stream));
+    h->pc4_base[0] = h->pc4_base[1] = 0;
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sched_cnt[0], (size_t)SCHED_BUCKETS))) return rc;
     if ((rc = dmalloc(&h->sched_cnt[1], (size_t)SCHED_BUCKETS))) return rc;
@@ -486,7 +495,7 @@ int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M
 {
     if (!st) st = h->stream;
     const size_t lds2 = (size_t)4 * cdiv(Kd, 16) * h->NB * 64 * sizeof(double);   // k_mm_rows2: W staged in LDS
-    if (h->mm_fast && ldx % 2 == 0 && lds2 <= 64 * 1024) {
+    if (h->mm_fast && M >= MM_FAST_MIN && ldx % 2 == 0 && lds2 <= 64 * 1024) {
         const int tiles = cdiv(M, 16), tpw = mm_tiles_per_wave(h, tiles);
         NB_DISPATCH(h->NB, {
             (void)WPB_;
@@ -513,7 +522,7 @@ int launch_mm_reduce_kp(insider_hip_handle *h, const double *X, int64_t ldx, con
     if (!st) st = h->stream;
     const int slabs = cdiv(M, MM_SLAB);
     if (nslab) *nslab = slabs;
-    if (h->mm_fast && L > 16) {   // several column tiles of X per wave, deeper look-ahead; the same partial sums (k_mm_reduce2)
+    if (h->mm_fast && M >= MM_FAST_MIN && L > 16) {   // several column tiles of X per wave, deeper look-ahead; the same partial sums (k_mm_reduce2)
         const int lt = cdiv(L, 16);
 #define MR2(NBV, LTV)                                                                                                         \
     hipLaunchKernelGGL((k_mm_reduce2<NBV, LTV>), dim3(slabs, cdiv(lt, LTV)), dim3(64), 0, st, X, ldx, Y, (int64_t)h->KP, M,   \
@@ -580,19 +589,22 @@ int phase_R(insider_hip_handle *h, bool use_side = false, bool r_is_current = fa
 {
     if (use_side) {
         HIPCHECK(hipEventRecord(h->ev_a_ready, h->stream));
+        // Qheld = S^held A, which the factored column statistics read: on the third stream (idle since the row phase's C'C),
+        // beside R'R on the main one instead of behind it, and beside Qfull on the side stream.  (join_lean bit 4 puts Qfull
+        // behind Qheld — alone, Qheld takes 22 instead of 33 us and the statistics start 11 us earlier — but Qfull then runs
+        // beside the statistics kernel and costs it 40 us of LDS and matrix time for its own 21: measured, round 5.)
         HIPCHECK(hipStreamWaitEvent(h->side, h->ev_a_ready, 0));
-        int rq = launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull, h->side);
-        if (rq) return rq;
-        HIPCHECK(hipEventRecord(h->ev_qfull, h->side));
-        h->qfull_pending = true;
-        // ... and so is Qheld = S^held A, which the factored column statistics read: on the third stream (idle since the row
-        // phase's C'C), beside R'R on the main one instead of behind it
         if (want_qheld && h->Qheld && use_col_factored(h)) {
             HIPCHECK(hipStreamWaitEvent(h->side3, h->ev_a_ready, 0));
             if (int rh = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld, h->side3)) return rh;
             HIPCHECK(hipEventRecord(h->ev_qheld, h->side3));
             h->qheld_pending = true;
+            if (h->join_lean & 4) HIPCHECK(hipStreamWaitEvent(h->side, h->ev_qheld, 0));
         }
+        int rq = launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull, h->side);
+        if (rq) return rq;
+        HIPCHECK(hipEventRecord(h->ev_qfull, h->side));
+        h->qfull_pending = true;
     }
     int rc = r_is_current ? INSIDER_OK : launch_build_R(h);
     if (rc) return rc;
@@ -741,18 +753,25 @@ int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipSt
 {
     if (h->col_mfma4 && h->NB <= 2 && !(a.zt && a.nsteps > 4)) {   // (real-valued counts with more than four k-steps: 180 registers, two waves per SIMD)
         // second product on the 4x4x4 matrix instruction, factor rows of every position staged in LDS (k_col_paircnt4);
-        // option value 2: one block per group of four genes
         size_t quads = 1;
         for (int t = 0; t < a.c + (a.zt ? 1 : 0); ++t) quads += (size_t)(a.L[t] + 3) / 4;
         const size_t lds = ((size_t)4 * 16 * 17 + (size_t)h->KP * h->KP + (size_t)4 * a.nsteps * h->KP + 4 * quads * h->KP) * sizeof(double);
         if (lds <= 64 * 1024) {
             // as many blocks as stay resident (48.6 KB of LDS at c3: three per CU); each walks the groups of four genes with the grid's stride
             const int resident = std::max(1, std::min((int)(160 * 1024 / lds), (a.zt && a.nsteps > 4) ? 2 : 3)) * std::max(1, h->n_simd / 4);   // registers: 148 - 166 (180 with real-valued counts and more than four k-steps)
-            const int nb = std::min(blocks, h->col_mfma4 >= 2 ? blocks : resident);
+            int nb = std::min(blocks, resident);
+            const int npart = nb >= PC4_PARTS ? PC4_PARTS : 1;      // ticket counters in use (k_col_paircnt4)
+            nb -= nb % npart;
+            const int nitems = a.list ? 4 * blocks : a.p;           // (a list launch: its bound; the kernel stops at *list_count)
+            const int cap = cdiv(nitems, npart);
+            const int which = st == h->lng ? 1 : 0;                 // the two launch sites may run at the same time: a set of counters each
+            unsigned *tk = h->pc4_ticket + (size_t)which * PC4_PARTS * 32;
+            const unsigned tbase = h->pc4_base[which];
+            h->pc4_base[which] += (unsigned)cap + 4u * (unsigned)(nb / npart);   // what this launch takes from each counter in use: its items and one ticket per wave
 #define PC4(NBV, MS)                                                                                                         \
     {                                                                                                                        \
-        if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, true>), dim3(nb), dim3(256), lds, st, a, blocks);           \
-        else hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, false>), dim3(nb), dim3(256), lds, st, a, blocks);               \
+        if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, true>), dim3(nb), dim3(256), lds, st, a, nitems, tk, tbase, npart, cap); \
+        else hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, false>), dim3(nb), dim3(256), lds, st, a, nitems, tk, tbase, npart, cap); \
     }
             if (h->NB == 1 && a.nsteps <= 4) PC4(1, 4)
             else if (h->NB == 1) PC4(1, 8)
@@ -864,10 +883,12 @@ int launch_col_solve(insider_hip_handle *h, int masked, bool solve, double lambd
 {
     const bool early = outer_iter >= 0 && outer_iter < insider_hip_handle::EARLY;
     const int NBLK = h->NB * (h->NB + 1) / 2, STAT = NBLK * 256;
-    if (h->side_pending) {   // the gene order / sweep-order table prepared on the side stream
+    // (every stream join is a barrier packet on the main queue, ~5 us of bubble each at c3: ev_qfull is recorded on the side stream
+    // AFTER the previous iteration's ev_side_done — phase_R comes after side_close — so it stands for both)
+    if (h->side_pending && !((h->join_lean & 2) && h->qfull_pending)) {   // the gene order / sweep-order table prepared on the side stream
         HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_side_done, 0));
-        h->side_pending = false;
     }
+    h->side_pending = false;
     if (h->qfull_pending) {
         HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_qfull, 0));
         h->qfull_pending = false;
@@ -1137,7 +1158,7 @@ int launch_gene_v(insider_hip_handle *h, int q_begin, int q_end)
     // V[:, q_begin:q_end) = C A[q_begin:q_end, :]'  (A given "transposed": one row per output column)
     const int N = q_end - q_begin;
     if (N <= 0) return INSIDER_OK;
-    if (h->mm_fast) {   // A' staged in LDS once per block, C read in 16-byte pieces (k_mm_rows2)
+    if (h->mm_fast && h->p >= MM_FAST_MIN) {   // A' staged in LDS once per block, C read in 16-byte pieces (k_mm_rows2)
         const int tiles = cdiv((int)h->p, 16), tpw = mm_tiles_per_wave(h, tiles);
         const size_t ldsb = (size_t)4 * cdiv(h->K, 16) * 64 * sizeof(double);
 #define GV2_LAUNCH(NT_)                                                                                                       \
@@ -1205,12 +1226,24 @@ int launch_level_gram(insider_hip_handle *h, int i, hipStream_t st, double *rec,
 #define WG_LAUNCH(LT_)                                                                                                     \
     hipLaunchKernelGGL((k_wgemm<LT_>), grid, dim3(256), 0, st, hn, h->cf.hn_stride, w.tiles, (const double *)h->C, h->KP,   \
                        (int)h->p, w.slab, w.nslab, (const uint8_t *)h->wg_pair, w.ntile, h->wg_part)
+#define WG4_LAUNCH(LT_)                                                                                                    \
+    hipLaunchKernelGGL((k_wgemm4<LT_>), grid, dim3(256), 0, st, hn, h->cf.hn_stride, w.tiles, (const double *)h->C, h->KP,  \
+                       (int)h->p, w.slab, w.nslab, (const uint8_t *)h->wg_pair, w.ntile, h->wg_part)
+        if (h->row_gemm4) {   // the same GEMM on the 4x4x4 matrix instruction
+            switch (w.LT) {
+                case 4: WG4_LAUNCH(4); break;
+                case 5: WG4_LAUNCH(5); break;
+                case 6: WG4_LAUNCH(6); break;
+                default: WG4_LAUNCH(7); break;
+            }
+        } else
         switch (w.LT) {
             case 4: WG_LAUNCH(4); break;
             case 5: WG_LAUNCH(5); break;
             case 6: WG_LAUNCH(6); break;
             default: WG_LAUNCH(7); break;
         }
+#undef WG4_LAUNCH
 #undef WG_LAUNCH
         KCHECK();
         hipLaunchKernelGGL(k_wgemm_sum, dim3(cdiv(stat_len, 256), ct.L), dim3(256), 0, st, (const double *)h->wg_part, w.nslab,
@@ -1253,6 +1286,9 @@ int launch_wsyrk_side(insider_hip_handle *h)
     for (int i = 0; i < h->c; ++i) {
         const int plen = h->NB * (h->NB + 1) / 2 * 256 + 2 * h->KP + 2;
         if (int rg = launch_level_gram(h, i, h->side2, h->lvl_sum_all + (size_t)h->lvl_off[i] * plen)) return rg;
+        // the level solves need C'C and (S^train C') as well: this stream joins the third one once, in front of its first event,
+        // so that every ev_w stands for ev_prep too and the main chain waits ONCE per covariate
+        if (i == 0 && (h->join_lean & 1)) HIPCHECK(hipStreamWaitEvent(h->side2, h->ev_prep, 0));
         HIPCHECK(hipEventRecord(h->ev_w[i], h->side2));
     }
     for (int k = 0; k < (h->cont_merged ? h->m : 0); ++k) {   // continuous columns: one-level covariates with real-valued weights
@@ -1314,7 +1350,7 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
         if (int rcy = launch_mm_reduce_kp(h, h->U, 2, h->C, (int)h->p, 1, h->sc_part, nullptr, nullptr, &ypart_n)) return rcy;
         if (h->w_ready) {
             HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[h->c + cont_col], 0));
-            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
+            if (!((h->join_lean & 1) && h->c > 0)) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
         }
         NB_DISPATCH(h->NB, {
             (void)WPB_;
@@ -1356,7 +1392,7 @@ int row_update(insider_hip_handle *h, int i, int cont_col, int masked, double la
         if (!h->row_fused) ypart_n = 0;
         if (h->w_ready) {   // wsyrk + level sums came from side2, C'C and (S^train C') from side3
             HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_w[i], 0));
-            HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
+            if (!(h->join_lean & 1)) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_prep, 0));
         }
         if (!h->w_ready)
             if (int rg = launch_level_gram(h, i, h->stream, h->lvl_sum)) return rg;
@@ -2246,6 +2282,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "row_counts") h->row_counts = (int)value;   // 1 = the merged row update takes u from the dense pair counts when they exist (default), 0 = from the entry lists
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
     else if (s == "row_gemm_waves") { h->wg_waves = std::max(64, (int)value); h->K = 0; }   // (re-plans the workspace)
+    else if (s == "row_gemm4") h->row_gemm4 = (int)value;     // 1 (default) = the level Gram GEMM on the 4x4x4 matrix instruction, 0 = 16x16x4 (k_wgemm)
     else if (s == "row_gemm") h->row_gemm = (int)value;       // 1 (default) = k_wgemm for covariates with >= 49 levels, 0 = k_wsyrk everywhere
     else if (s == "row_head") h->row_head = (int)value;       // 1 (default) = the main chain's k_gene_u is dispatched behind the level Gram GEMM (launch_wsyrk_side)
     else if (s == "row_fused") h->row_fused = (int)value;     // 1 (default) = k_level_merged (one launch per covariate), 0 = k_level_pack / k_level_reduce / k_level_solve
@@ -2253,6 +2290,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
     else if (s == "list_fine") h->list_fine = (int)value;       // 1 (default) = per-entry statistics on v_mfma_f64_4x4x4 for 16 <= K <= 31, 0 = on 16x16x4
+    else if (s == "join_lean") h->join_lean = (int)value;         // experiment of round 5, off: bits 1 | 2 gain 0.6 % at c3 and cost c2 2.5 % (chained joins add their wake-up latencies)
     else if (s == "mm_fast") h->mm_fast = (int)value;             // 0 = k_mm_rows / k_mm_reduce as in round 4
     else if (s == "col_mfma4") h->col_mfma4 = (int)value;         // 1 = k_col_paircnt4 (K <= 31, factor rows fit LDS), 0 = k_col_paircnt
     else if (s == "cd_pairs") h->cd_pairs = (int)value;           // 1 (default) = sweeps routed through the blocks of two coordinate steps (K <= 30; same iterates), 0 = one step per block
