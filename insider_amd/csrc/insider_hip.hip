@@ -174,7 +174,6 @@ struct insider_hip_handle {
     int max_items = 0;
     bool merged = false;              // the merged masked row update is available (categorical covariates only)
     int row_merged = 1;               // option: use it
-    int row_gemm4 = 1;                // option "row_gemm4": k_wgemm4 (v_mfma_f64_4x4x4) instead of k_wgemm
     int row_gemm = 1;                 // option "row_gemm": weighted SYRK of a many-level covariate as one GEMM over genes (k_wgemm)
     double *wg_part = nullptr;        // its per-slab partial sums
     int wg_waves = 1024;              // option "row_gemm_waves": waves the GEMM is cut into (sets the number of gene slabs)
@@ -1226,24 +1225,12 @@ int launch_level_gram(insider_hip_handle *h, int i, hipStream_t st, double *rec,
 #define WG_LAUNCH(LT_)                                                                                                     \
     hipLaunchKernelGGL((k_wgemm<LT_>), grid, dim3(256), 0, st, hn, h->cf.hn_stride, w.tiles, (const double *)h->C, h->KP,   \
                        (int)h->p, w.slab, w.nslab, (const uint8_t *)h->wg_pair, w.ntile, h->wg_part)
-#define WG4_LAUNCH(LT_)                                                                                                    \
-    hipLaunchKernelGGL((k_wgemm4<LT_>), grid, dim3(256), 0, st, hn, h->cf.hn_stride, w.tiles, (const double *)h->C, h->KP,  \
-                       (int)h->p, w.slab, w.nslab, (const uint8_t *)h->wg_pair, w.ntile, h->wg_part)
-        if (h->row_gemm4) {   // the same GEMM on the 4x4x4 matrix instruction
-            switch (w.LT) {
-                case 4: WG4_LAUNCH(4); break;
-                case 5: WG4_LAUNCH(5); break;
-                case 6: WG4_LAUNCH(6); break;
-                default: WG4_LAUNCH(7); break;
-            }
-        } else
         switch (w.LT) {
             case 4: WG_LAUNCH(4); break;
             case 5: WG_LAUNCH(5); break;
             case 6: WG_LAUNCH(6); break;
             default: WG_LAUNCH(7); break;
         }
-#undef WG4_LAUNCH
 #undef WG_LAUNCH
         KCHECK();
         hipLaunchKernelGGL(k_wgemm_sum, dim3(cdiv(stat_len, 256), ct.L), dim3(256), 0, st, (const double *)h->wg_part, w.nslab,
@@ -2282,7 +2269,6 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "row_counts") h->row_counts = (int)value;   // 1 = the merged row update takes u from the dense pair counts when they exist (default), 0 = from the entry lists
     else if (s == "row_merged") h->row_merged = (int)value;   // 1 = merged masked row update when the time model favours it (default), 2 = always, 0 = per-sample statistics
     else if (s == "row_gemm_waves") { h->wg_waves = std::max(64, (int)value); h->K = 0; }   // (re-plans the workspace)
-    else if (s == "row_gemm4") h->row_gemm4 = (int)value;     // 1 (default) = the level Gram GEMM on the 4x4x4 matrix instruction, 0 = 16x16x4 (k_wgemm)
     else if (s == "row_gemm") h->row_gemm = (int)value;       // 1 (default) = k_wgemm for covariates with >= 49 levels, 0 = k_wsyrk everywhere
     else if (s == "row_head") h->row_head = (int)value;       // 1 (default) = the main chain's k_gene_u is dispatched behind the level Gram GEMM (launch_wsyrk_side)
     else if (s == "row_fused") h->row_fused = (int)value;     // 1 (default) = k_level_merged (one launch per covariate), 0 = k_level_pack / k_level_reduce / k_level_solve

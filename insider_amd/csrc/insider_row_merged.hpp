@@ -369,117 +369,10 @@ k_wgemm(const float *__restrict__ hn, int hn_stride, int lt_total, const double 
         }
 }
 
-// k_wgemm on v_mfma_f64_4x4x4 (round 5).  The 16x16x4 instruction retires once per ~100 cycles chip-wide where its 2048 flop
-// are 64 cycles of the matrix unit (tools/ubench_mfma4.hip: 0.60 of nominal); the 4x4x4 form — four independent 4 x 4 x 4
-// products, 16 cycles — sustains 0.93, and k_wgemm is bound by exactly that rate (2563 instructions per SIMD at c3 = 111 of its
-// 119 us alone).  Operand map (k_list_stats4): A[b][i][k] in lane 16 k + 4 b + i, B[b][k][j] in lane 16 k + 4 b + j, D[b][i][j] in
-// lane 16 i + 4 b + j.  With lane = (g4, c16 = 4 b + i): the count operand as k_wgemm loads it (gene g4 of the step, level c16 of
-// the tile) IS an A operand whose block b holds levels 4 b .. 4 b + 3; a pair-product register (gene g4, pair c16 of the tile) IS
-// a B operand whose block b holds pairs 4 b .. 4 b + 3: one instruction = the four diagonal 4 x 4 tiles of a (level tile, pair
-// tile) block.  The other twelve come from the same products rotated by 4 x lanes within each row of 16, x = 1 .. 3 (two
-// v_mov_dpp row_ror per product and rotation: 12 vector instructions per step of four genes beside 56 matrix instructions of 16
-// cycles; forming the rotated products from C instead — two more loads and a multiply each — ran 190 us against k_wgemm's 128:
-// 23 gathers per step on one wave per SIMD): block b then owns pair group (b + x) mod 4.  acc[l][t][x] of lane (g4, b, j) = G[level 16 (lt0 + l) + 4 b + g4][pair 16 (T0 + t) + 4 ((b + x) & 3) + j].
-// Same grid, slabs and partial-sum record as k_wgemm; sums over the genes of a slab in the same order (four per instruction).
-// lane i of every row of 16 <- lane (i + 16 - N) mod 16 of v (DPP row_ror:N)
-template <int N>
-__device__ __forceinline__ double row_ror(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-template <int LT>
-__global__ void __launch_bounds__(256)
-k_wgemm4(const float *__restrict__ hn, int hn_stride, int lt_total, const double *__restrict__ C, int KP, int p, int slab, int nslab,
-         const uint8_t *__restrict__ pair_ab /*[2][16 ntile]*/, int ntile, double *__restrict__ part /*[slabs][16 lt_total][16 ntile]*/)
-{
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int per = (ntile + 1) >> 1;
-    const int W = blockIdx.x * 4 + w;
-    if (W >= per * nslab) return;
-    const int slab_id = W / per;
-    const int T0 = (W - slab_id * per) * 2;
-    const int lt0 = blockIdx.z * LT;
-    const int g4 = lane >> 4, c16 = lane & 15;
-    const int j_begin = slab_id * slab, j_end = j_begin + slab < p ? j_begin + slab : p;
-    unsigned off_a[2], off_b[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int T = T0 + t < ntile ? T0 + t : ntile - 1;
-        off_a[t] = 8u * (unsigned)(g4 * KP + pair_ab[16 * T + c16]);
-        off_b[t] = 8u * (unsigned)(g4 * KP + pair_ab[16 * ntile + 16 * T + c16]);
-    }
-    const unsigned off_n = 4u * (unsigned)(g4 * hn_stride + (c16 & 3) * 4 + (c16 >> 2));   // level c16 of a tile, gene g4 of a step
-    double acc[LT][2][4];
-#pragma unroll
-    for (int l = 0; l < LT; ++l)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) acc[l][t][x] = 0.0;
-    struct Ops { float n[LT]; double ca[2], cb[2]; };
-    auto fetch = [&](int j0, Ops &o) {
-        const char *hb = reinterpret_cast<const char *>(hn + (size_t)j0 * hn_stride + 16 * lt0);
-        const char *cb = reinterpret_cast<const char *>(C + (size_t)j0 * KP);
-#pragma unroll
-        for (int l = 0; l < LT; ++l) o.n[l] = *reinterpret_cast<const float *>(hb + off_n + 64 * l);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            o.ca[t] = *reinterpret_cast<const double *>(cb + off_a[t]);
-            o.cb[t] = *reinterpret_cast<const double *>(cb + off_b[t]);
-        }
-    };
-    auto compute = [&](const Ops &o) {
-        double b[2][4];   // rotation x: this lane holds the product of pair (c16 + 4 x) mod 16 of the tile
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            b[t][0] = o.ca[t] * o.cb[t];
-            b[t][1] = row_ror<12>(b[t][0]);
-            b[t][2] = row_ror<8>(b[t][0]);
-            b[t][3] = row_ror<4>(b[t][0]);
-        }
-#pragma unroll
-        for (int l = 0; l < LT; ++l) {
-            const double a = (double)o.n[l];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) acc[l][t][x] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[t][x], acc[l][t][x], 0, 0, 0);
-        }
-    };
-    // three operand sets, as in k_wgemm: the loads of the next TWO steps of four genes are in flight
-    Ops o0, o1, o2;
-    if (j_begin < j_end) fetch(j_begin, o0);
-    if (j_begin + 4 < j_end) fetch(j_begin + 4, o1);
-    for (int j0 = j_begin; j0 < j_end; j0 += 12) {
-        if (j0 + 8 < j_end) fetch(j0 + 8, o2);
-        compute(o0);
-        if (j0 + 4 < j_end) {
-            if (j0 + 12 < j_end) fetch(j0 + 12, o0);
-            compute(o1);
-            if (j0 + 8 < j_end) {
-                if (j0 + 16 < j_end) fetch(j0 + 16, o1);
-                compute(o2);
-            }
-        }
-    }
-    double *out = part + (size_t)slab_id * (16 * lt_total) * (16 * ntile);
-    const int bq = c16 >> 2, jj = c16 & 3;
-#pragma unroll
-    for (int l = 0; l < LT; ++l)
-        if (lt0 + l < lt_total) {   // wave-uniform
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                if (T0 + t < ntile) {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        out[(size_t)(16 * (lt0 + l) + 4 * bq + g4) * (16 * ntile) + 16 * (T0 + t) + 4 * ((bq + x) & 3) + jj] = acc[l][t][x];
-                }
-        }
-}
-
+// (Round 5 built this GEMM on v_mfma_f64_4x4x4 as well — k_wgemm4, commit 5e6b267: count operand as the A operand, the pair
+// products rotated by 4 x lanes for the twelve off-diagonal 4 x 4 tiles — and it ran 141 us (rotations by DPP) / 190 us (rotated
+// products formed from C: 23 gathers per step) where this kernel takes 128 beside k_gene_u_cnt: the segment is bound by what the
+// two kernels need together, not by this one's matrix rate.  profiles/r05/exp/ab_wgemm_4x4x4_*.log.)
 // rec[l][e] for every entry e of the level record's lower 16 x 16 blocks: 2 sum_slabs part[slab][l][pair(a, b)] inside the
 // K x K part (slab order; pair(a, b) = hi (hi + 1) / 2 + lo, the packing of the table k_wgemm reads), 0 in the padding
 __global__ void __launch_bounds__(256) k_wgemm_sum(const double *__restrict__ part, int nslab, int lt_total, int ntile, int K,
