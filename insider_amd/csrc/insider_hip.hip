@@ -119,7 +119,8 @@ struct insider_hip_handle {
     double *lvl_sum_all = nullptr;    // [SLcat][STAT + 2 KP + 2]: the level records of every covariate
     bool w_ready = false;
     double *gram_part2 = nullptr, *sc_part2 = nullptr;   // partial-sum buffers of the side-stream products
-    hipEvent_t ev_a_ready = nullptr, ev_qfull = nullptr, ev_qheld = nullptr;
+    hipEvent_t ev_a_ready = nullptr, ev_qfull = nullptr, ev_qheld = nullptr, ev_q_early = nullptr;
+    int q_kb = 0;                     // rows [0, q_kb) of the stacked factors already sit in Qfull / Qheld (launch_q_early); 0: none
     bool qfull_pending = false;
     bool qheld_pending = false;       // Qheld = S^held A of the factored column statistics is being formed on side3 (phase_R)
     int64_t n = 0, p = 0, ldn = 0, ldp = 0;
@@ -189,6 +190,7 @@ struct insider_hip_handle {
     // order table holds absolute block addresses (insider_cd_reg.hpp), published by a probe launch of that kernel
     unsigned long long cd_code_base = 0, cd_pair_base = 0;
     unsigned long long *code_base_dev = nullptr;   // where the probe launch stores them (workspace)
+    int q_split = 0;                   // option "q_split" (experiment of round 5, off: no gain — the early parts slow the memory-bound kernels of the last update by what they save): Qfull / Qheld in two parts, the first beside the last block of the row phase (launch_q_early)
     int join_lean = 0;                 // option "join_lean" (bits): 1 = ev_prep behind ev_w, 2 = ev_side_done behind ev_qfull (one stream join where two were), 4 = Qfull behind Qheld
     int mm_fast = 1;                   // option "mm_fast": the small dense products on k_mm_rows2 / k_mm_reduce2 (default; 2: two column tiles per wave in the reductions)
     int col_mfma4 = 1;                 // option "col_mfma4": pair-count statistics with the second product on v_mfma_f64_4x4x4 (k_col_paircnt4; default)
@@ -489,21 +491,32 @@ int launch_list_stats(insider_hip_handle *h, bool cols, int nseg, const double *
 int mm_tiles_per_wave(const insider_hip_handle *h, int tiles) { return std::max(1, tiles / (2 * h->n_simd)); }
 
 // out[M x KP] = X[M x Kd] W[Kd x KP]   (W row-major with pitch KP)
+bool mm_rows2_fits(const insider_hip_handle *h, int64_t ldx, int M, int Kd)
+{
+    return h->mm_fast && M >= MM_FAST_MIN && ldx % 2 == 0 && (size_t)4 * cdiv(Kd, 16) * h->NB * 64 * sizeof(double) <= 64 * 1024;
+}
+// k_begin / k_end: a window of the inner dimension (columns of X, rows of W), k_begin even; accumulate: out += the window's
+// product.  Only with k_mm_rows2 (mm_rows2_fits); the default is the whole product
 int launch_mm_rows_kp(insider_hip_handle *h, const double *X, int64_t ldx, int M, int Kd, const double *W, double *out,
-                      hipStream_t st = nullptr)
+                      hipStream_t st = nullptr, int k_begin = 0, int k_end = -1, bool accumulate = false)
 {
     if (!st) st = h->stream;
-    const size_t lds2 = (size_t)4 * cdiv(Kd, 16) * h->NB * 64 * sizeof(double);   // k_mm_rows2: W staged in LDS
-    if (h->mm_fast && M >= MM_FAST_MIN && ldx % 2 == 0 && lds2 <= 64 * 1024) {
+    if (k_end < 0) k_end = Kd;
+    const bool window = k_begin != 0 || k_end != Kd || accumulate;
+    const size_t lds2 = (size_t)4 * cdiv(k_end - k_begin, 16) * h->NB * 64 * sizeof(double);   // k_mm_rows2: W staged in LDS
+    if (mm_rows2_fits(h, ldx, M, Kd) && k_begin % 2 == 0) {
         const int tiles = cdiv(M, 16), tpw = mm_tiles_per_wave(h, tiles);
+        const int kread = (int)((ldx - k_begin) & ~(int64_t)1);
         NB_DISPATCH(h->NB, {
             (void)WPB_;
-            hipLaunchKernelGGL((k_mm_rows2<NB_, false>), dim3(cdiv(cdiv(tiles, tpw), 4), 1), dim3(256), lds2, st, X, ldx, M, Kd, W,
-                               h->KP, h->KP, out, (int64_t)h->KP, h->KP, tpw);
+            hipLaunchKernelGGL((k_mm_rows2<NB_, false>), dim3(cdiv(cdiv(tiles, tpw), 4), 1), dim3(256), lds2, st, X + k_begin, ldx, M,
+                               k_end - k_begin, W + (size_t)k_begin * h->KP, h->KP, h->KP, out, (int64_t)h->KP, h->KP, tpw, kread,
+                               accumulate ? 1 : 0);
         });
         KCHECK();
         return INSIDER_OK;
     }
+    if (window) return fail(INSIDER_ERR_ARG, "a window of the product needs k_mm_rows2");
     NB_DISPATCH(h->NB, {
         (void)WPB_;
         hipLaunchKernelGGL((k_mm_rows<NB_, false>), dim3(cdiv(cdiv(M, 16), 4), 1), dim3(256), 0, st, X, ldx, M, Kd, W,
@@ -592,15 +605,19 @@ int phase_R(insider_hip_handle *h, bool use_side = false, bool r_is_current = fa
         // beside R'R on the main one instead of behind it, and beside Qfull on the side stream.  (join_lean bit 4 puts Qfull
         // behind Qheld — alone, Qheld takes 22 instead of 33 us and the statistics start 11 us earlier — but Qfull then runs
         // beside the statistics kernel and costs it 40 us of LDS and matrix time for its own 21: measured, round 5.)
+        // (launch_q_early: the rows [0, kb) of the stacked factors, final since the second-to-last update of the row phase, are
+        // already in both products — formed beside the last update; only the last block's columns are left)
+        const int kb = h->q_kb;
+        h->q_kb = 0;
         HIPCHECK(hipStreamWaitEvent(h->side, h->ev_a_ready, 0));
         if (want_qheld && h->Qheld && use_col_factored(h)) {
             HIPCHECK(hipStreamWaitEvent(h->side3, h->ev_a_ready, 0));
-            if (int rh = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld, h->side3)) return rh;
+            if (int rh = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld, h->side3, kb, h->SL, kb > 0)) return rh;
             HIPCHECK(hipEventRecord(h->ev_qheld, h->side3));
             h->qheld_pending = true;
             if (h->join_lean & 4) HIPCHECK(hipStreamWaitEvent(h->side, h->ev_qheld, 0));
         }
-        int rq = launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull, h->side);
+        int rq = launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull, h->side, kb, h->SL, kb > 0);
         if (rq) return rq;
         HIPCHECK(hipEventRecord(h->ev_qfull, h->side));
         h->qfull_pending = true;
@@ -611,6 +628,29 @@ int phase_R(insider_hip_handle *h, bool use_side = false, bool r_is_current = fa
     if (rc) return rc;
     if (use_side) return INSIDER_OK;
     return launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull);
+}
+
+// Qfull = S A and Qheld = S^held A by parts (option "q_split"): the product over the rows [0, kb) of the stacked factors —
+// every block of the row phase but its last — is formed on the side streams as soon as those rows are final, beside the last
+// block's update (small dependent kernels that leave the machine idle); phase_R then adds the last block's columns.  At c3
+// (100 + 10 levels) that leaves 10 of 110 columns behind the row phase: 8 instead of 33 us in front of the column statistics.
+// Sums over the stacked levels in two runs [0, kb), [kb, SL) instead of one: agrees with the one-piece product to rounding.
+int q_split_boundary(const insider_hip_handle *h, int masked, bool cont_follow)
+{
+    if (!h->q_split || !masked || !h->Qheld || !use_col_factored(h)) return 0;
+    const int kb = cont_follow ? h->SLcat : (h->c >= 2 ? h->lvl_off[h->c - 1] : 0);
+    if (kb < 16 || kb % 2 != 0 || kb >= h->SL || !mm_rows2_fits(h, h->SLP, (int)h->p, h->SL)) return 0;
+    return kb;
+}
+int launch_q_early(insider_hip_handle *h, int kb)
+{
+    HIPCHECK(hipEventRecord(h->ev_q_early, h->stream));
+    HIPCHECK(hipStreamWaitEvent(h->side3, h->ev_q_early, 0));
+    if (int rh = launch_mm_rows_kp(h, h->Sheld, h->SLP, (int)h->p, h->SL, h->Astack, h->Qheld, h->side3, 0, kb, false)) return rh;
+    HIPCHECK(hipStreamWaitEvent(h->side, h->ev_q_early, 0));
+    if (int rq = launch_mm_rows_kp(h, h->S, h->SLP, (int)h->p, h->SL, h->Astack, h->Qfull, h->side, 0, kb, false)) return rq;
+    h->q_kb = kb;
+    return INSIDER_OK;
 }
 
 struct Timer {   // HIP-event pair around one launch on the library's stream (option "profile")
@@ -1163,7 +1203,7 @@ int launch_gene_v(insider_hip_handle *h, int q_begin, int q_end)
 #define GV2_LAUNCH(NT_)                                                                                                       \
     hipLaunchKernelGGL((k_mm_rows2<NT_, true>), dim3(cdiv(cdiv(tiles, tpw), 4), cdiv(N, 16 * NT_)), dim3(256), ldsb * NT_, h->stream, \
                        (const double *)h->C, (int64_t)h->KP, (int)h->p, h->K,                                                \
-                       (const double *)(h->Astack + (size_t)q_begin * h->KP), h->KP, N, h->Vlev + q_begin, (int64_t)h->SLP, N, tpw)
+                       (const double *)(h->Astack + (size_t)q_begin * h->KP), h->KP, N, h->Vlev + q_begin, (int64_t)h->SLP, N, tpw, h->KP, 0)
         if (N <= 16) GV2_LAUNCH(1);
         else if (N <= 32) GV2_LAUNCH(2);
         else GV2_LAUNCH(4);
@@ -1630,6 +1670,7 @@ hipError_t make_streams(insider_hip_handle *h)
     MS(hipEventCreateWithFlags(&h->ev_a_ready, EV_SYNC));
     MS(hipEventCreateWithFlags(&h->ev_qfull, EV_SYNC));
     MS(hipEventCreateWithFlags(&h->ev_qheld, EV_SYNC));
+    MS(hipEventCreateWithFlags(&h->ev_q_early, EV_SYNC));
     h->ev_w.assign((h->c > 0 ? h->c : 1) + h->m, nullptr);
     for (auto &ev : h->ev_w) MS(hipEventCreateWithFlags(&ev, EV_SYNC));
     MS(hipEventCreateWithFlags(&h->ev_cd_done, EV_SYNC));
@@ -1643,7 +1684,7 @@ void destroy_streams(insider_hip_handle *h)
 {
     for (hipStream_t *st : {&h->side, &h->side2, &h->side3, &h->lng}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
     for (hipEvent_t *ev : {&h->ev_long_go, &h->ev_long_done, &h->ev_prep, &h->ev_c_ready, &h->ev_head, &h->ev_a_ready, &h->ev_qfull, &h->ev_qheld, &h->ev_cd_done,
-                           &h->ev_side_done, &h->ev_tab}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
+                           &h->ev_side_done, &h->ev_tab, &h->ev_q_early}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
     for (auto ev : h->ev_w) if (ev) (void)hipEventDestroy(ev);
     h->ev_w.clear();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1710,10 +1751,12 @@ int insider_hip_clone(insider_hip_handle *src, insider_hip_handle **out)
     forget_workspace(h);                                    // (the copied pointers are the source's buffers)
     h->stream = h->side = h->side2 = h->side3 = h->lng = nullptr;
     h->ev_long_go = h->ev_long_done = h->ev_prep = h->ev_c_ready = h->ev_head = h->ev_a_ready = h->ev_qfull = h->ev_qheld = nullptr;
-    h->ev_cd_done = h->ev_side_done = h->ev_tab = nullptr;
+    h->ev_cd_done = h->ev_side_done = h->ev_tab = h->ev_q_early = nullptr;
+    h->q_kb = 0;
     h->ev_w.clear();
     for (auto *v : {&h->ev_col, &h->ev_row, &h->ev_cd, &h->ev_test}) v->clear();
     h->side_pending = h->w_ready = h->qfull_pending = h->qheld_pending = h->long_pending = false;
+    h->q_kb = 0;
     h->comm = nullptr;                                      // a sharded clone joins its own communicator (insider_hip_comm_init)
     for (double &v : h->prof) v = 0.0;
     h->steady_cd_ms = h->steady_col_ms = 0.0;
@@ -2276,6 +2319,7 @@ int insider_hip_set_option(insider_hip_handle *h, const char *name, double value
     else if (s == "cd_pass1") h->cd_pass_first = (int)value;        // sweep index where the first pass stops (0 = single pass)
     else if (s == "cd_pass_ratio") h->cd_pass_ratio = (int)value;   // each further pass stops at ratio x the previous limit
     else if (s == "list_fine") h->list_fine = (int)value;       // 1 (default) = per-entry statistics on v_mfma_f64_4x4x4 for 16 <= K <= 31, 0 = on 16x16x4
+    else if (s == "q_split") h->q_split = (int)value;             // 0 = both products in one piece behind the row phase
     else if (s == "join_lean") h->join_lean = (int)value;         // experiment of round 5, off: bits 1 | 2 gain 0.6 % at c3 and cost c2 2.5 % (chained joins add their wake-up latencies)
     else if (s == "mm_fast") h->mm_fast = (int)value;             // 0 = k_mm_rows / k_mm_reduce as in round 4
     else if (s == "col_mfma4") h->col_mfma4 = (int)value;         // 1 = k_col_paircnt4 (K <= 31, factor rows fit LDS), 0 = k_col_paircnt
@@ -2307,6 +2351,7 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
     h->side_pending = false;
     h->qfull_pending = false;
     h->qheld_pending = false;
+    h->q_kb = 0;
     h->long_pending = false;
     const int masked = tuning == 1;
     if ((rc = upload_factors(h, A, C, K))) return rc;
@@ -2358,11 +2403,14 @@ static int optimize_body(insider_hip_handle *h, double *const *A, double *C, int
 #endif
         if (use_merged(h, masked) && h->row_head) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_head, 0));   // launch_wsyrk_side
         const bool cont_follow = inc_continuous && h->m > 0;
+        const int q_kb = use_merged(h, masked) ? q_split_boundary(h, masked, cont_follow) : 0;
         for (int i = 0; i < h->c; ++i) {
             const bool need_R = !(use_merged(h, masked) || unmasked_fused(h, masked)) || (i + 1 == h->c && !cont_follow);
             if ((rc = row_update(h, i, -1, masked, lambda1, need_R))) return rc;                // :339
             if (use_merged(h, masked) && (i + 1 < h->c || cont_follow))   // (the continuous columns read every categorical column of V)
                 if ((rc = launch_gene_v(h, h->lvl_off[i], h->lvl_off[i + 1]))) return rc;
+            if (q_kb && i + (cont_follow ? 1 : 2) == h->c)   // every block but the last is final: its part of Qfull / Qheld, beside the last update
+                if ((rc = launch_q_early(h, q_kb))) return rc;
         }
         if (cont_follow)
             for (int j = 0; j < h->m; ++j) {
@@ -2486,6 +2534,7 @@ int insider_hip_optimize(insider_hip_handle *h, double *const *A, double *C, int
         (void)hipStreamSynchronize(h->side3);
         (void)hipStreamSynchronize(h->lng);
         h->side_pending = h->qfull_pending = h->qheld_pending = h->w_ready = h->long_pending = false;
+        h->q_kb = 0;
         if (h->failflag) (void)hipMemset(h->failflag, 0, 4 * sizeof(int));
         clear_events(h);
         g_err = keep;

@@ -104,12 +104,14 @@ __global__ void __launch_bounds__(64) k_mm_reduce(const double *__restrict__ X, 
 // ds_read_b64 per instruction), a lane reads its row of X in 16-byte pieces — four consecutive k per lane and chunk of 16, so the
 // k of MFMA step e of chunk S are 16 S + 4 g + e (g = lane >> 4): the staged W follows the same map — all loads of up to eight
 // chunks are issued before the first MFMA, and a wave takes tiles_per_wave consecutive tiles of 16 rows.  Sums over k in
-// another order than k_mm_rows: results agree to rounding.  X rows must be 16-byte aligned (ldx even).
+// another order than k_mm_rows: results agree to rounding.  X rows must be 16-byte aligned (X, ldx and kread even).
 template <int NT, bool WT>
 __global__ void __launch_bounds__(256) k_mm_rows2(const double *__restrict__ X, int64_t ldx, int M, int Kd,
                                                   const double *__restrict__ W, int ldw, int N, double *__restrict__ out,
-                                                  int64_t ldo, int n_store, int tiles_per_wave)
+                                                  int64_t ldo, int n_store, int tiles_per_wave, int kread, int accumulate)
 {
+    // kread: columns that may be read from a row of X as given (ldx, or less when X points into a row: a column window of the
+    // product); accumulate: out += (the window's product) instead of out =
     extern __shared__ double s_w[];   // [4 nchunk][NT][64]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c16 = lane & 15;
@@ -131,6 +133,15 @@ __global__ void __launch_bounds__(256) k_mm_rows2(const double *__restrict__ X, 
         d4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        if (accumulate) {   // wave-uniform
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + g + 4 * r, n = nb + 16 * t + c16;
+                    if (m < M && n < N) acc[t][r] = out[(size_t)m * ldo + n];
+                }
+        }
         for (int S0 = 0; S0 < nchunk; S0 += 8) {
             double x[8][4];
 #pragma unroll
@@ -138,8 +149,8 @@ __global__ void __launch_bounds__(256) k_mm_rows2(const double *__restrict__ X, 
                 if (S0 + S < nchunk) {   // wave-uniform
                     const int k4 = 16 * (S0 + S) + 4 * g;
                     double2 lo = {0.0, 0.0}, hi = {0.0, 0.0};
-                    if (k4 < ldx) lo = *reinterpret_cast<const double2 *>(xr + 16 * (S0 + S));
-                    if (k4 + 2 < ldx) hi = *reinterpret_cast<const double2 *>(xr + 16 * (S0 + S) + 2);
+                    if (k4 + 1 < kread) lo = *reinterpret_cast<const double2 *>(xr + 16 * (S0 + S));
+                    if (k4 + 3 < kread) hi = *reinterpret_cast<const double2 *>(xr + 16 * (S0 + S) + 2);
                     x[S][0] = lo.x; x[S][1] = lo.y; x[S][2] = hi.x; x[S][3] = hi.y;
                     if (16 * (S0 + S) + 16 > Kd) {   // the last chunk: what lies beyond Kd in the row is not part of the product
 #pragma unroll
