@@ -404,7 +404,7 @@ def main():
         b_gram = 8.0 * n * p_loc + 1.0 * n * p_loc + 8.0 * n * K + 8.0 * p_loc * (T + K)
         fl_alg = 2.0 * f * n * p_loc * T + 2.0 * f * n * p_loc * K
         path = int(ds.info("col_stats_path")) if tuning == 1 else -1
-        kern = {2: "k_col_paircnt, pair-count form (its k_mm_rows product, held-out level sums x row factors, forms beside R'R on another stream since round 5 and is no longer inside this launch time)",
+        kern = {2: "k_col_paircnt4 (K <= 31: second product on v_mfma_f64_4x4x4, factor rows in LDS, genes by ticket; else k_col_paircnt), pair-count form (its k_mm_rows2 product, held-out level sums x row factors, forms beside R'R on another stream since round 5 and is not inside this launch time)",
                 1: "k_col_factored, look-up form (k_mm_rows product beside R'R on another stream)", 0: "k_list_stats4 / k_list_stats, one rank-one matrix-unit term per held-out entry (v_mfma_f64_4x4x4 tiles for 16 <= K <= 31, else 16x16x4 blocks)",
                 -1: "none (tuning = 0: shared R'R, no masked statistics)"}[path]
         mfma_gene = ds.info("col_mfma_per_gene") if tuning == 1 else 0.0

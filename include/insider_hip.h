@@ -138,7 +138,12 @@ int insider_hip_comm_init(insider_hip_handle *h, const void *unique_id, int rank
  * levels come from one GEMM over genes, cut into row_gemm_waves [1024] waves; 0 = one weighted rank-one update per (level, gene);
  * same sums in another order, results agree to rounding), "col_mfma4" (1, default = the pair-count column statistics [K <= 31, the
  * factor rows of all covariates within 64 KB of LDS] form sum_l a_l p_l' on the 4x4x4 form of the f64 matrix instruction, rows read
- * in four rotations from LDS, resident blocks walking the genes; 0 = the 16x16x4 form; same sums to rounding), "cd_pairs" (1, default = the register-resident sweep kernel [K <= 30] is routed through its blocks of TWO
+ * in four rotations from LDS, resident blocks whose waves draw genes by ticket; 0 = the 16x16x4 form; same sums to rounding),
+ * "mm_fast" (1, default = the streaming products of the row phase [V = C A', S A, U'C, S'C: from 16384 rows on] stage their small
+ * operand in LDS once per block and read the tall one in 16-byte pieces / several column tiles per wave; 0 = round 4's kernels;
+ * same sums, the row products in another order), "join_lean" and "q_split" (0: experiments of round 5 that gained nothing — fewer
+ * stream joins on the main chain [bits 1, 2, 4]; S A and S^held A in two parts, the first beside the last covariate's update),
+ * "cd_pairs" (1, default = the register-resident sweep kernel [K <= 30] is routed through its blocks of TWO
  * coordinate steps wherever two consecutive coordinates of a sweep's order share a coordinate slot: a third fewer computed jumps,
  * the same steps in the same order — bit-identical iterates; 0 = one step per block), "cd_pass1" / "cd_pass_ratio" / "cd_cold_iters" (multi-pass column solves in the first
  * cd_cold_iters outer iterations of a call [default 3]: the register-resident sweep kernel stops at sweep cd_pass1 [64; 0 = one

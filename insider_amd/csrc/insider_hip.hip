@@ -185,7 +185,7 @@ struct insider_hip_handle {
     int *sweep_key = nullptr;   // smoothed sweep counts: the longest-first scheduling key (k_sched_bucket)
     unsigned long long *sweep_total = nullptr;
     unsigned *pc4_ticket = nullptr;     // k_col_paircnt4's gene tickets (main launch, long-gene launch): counters that only grow
-    unsigned pc4_base[2] = {0, 0};      // ... and the value each stands at when its next launch starts
+    unsigned pc4_base[4] = {0, 0, 0, 0};   // ... and the value each set stands at when its next launch starts: [2 site + (one counter ? 1 : 0)]
     // where the register-resident sweep kernel of the current K keeps its table of code blocks (K <= 32; 0 = not asked yet): the
     // order table holds absolute block addresses (insider_cd_reg.hpp), published by a probe launch of that kernel
     unsigned long long cd_code_base = 0, cd_pair_base = 0;
@@ -410,9 +410,9 @@ int ensure_workspace(insider_hip_handle *h, int K)
     // [0] a system was singular, [1] ridge genes wait for the general route, [2] genes stopped by max_sweeps, [3] longest solve
     if ((rc = dmalloc(&h->failflag, 4))) return rc;
     if ((rc = dmalloc(&h->sweep_total, 256))) return rc;
-    if ((rc = dmalloc(&h->pc4_ticket, (size_t)2 * PC4_PARTS * 32))) return rc;   // (a 128-byte line per counter)
-    HIPCHECK(hipMemsetAsync(h->pc4_ticket, 0, (size_t)2 * PC4_PARTS * 32 * sizeof(unsigned), h->stream));
-    h->pc4_base[0] = h->pc4_base[1] = 0;
+    if ((rc = dmalloc(&h->pc4_ticket, (size_t)2 * (PC4_PARTS + 1) * 32))) return rc;   // (a 128-byte line per counter)
+    HIPCHECK(hipMemsetAsync(h->pc4_ticket, 0, (size_t)2 * (PC4_PARTS + 1) * 32 * sizeof(unsigned), h->stream));
+    for (unsigned &b : h->pc4_base) b = 0;
     if ((rc = dmalloc(&h->gene_perm, (size_t)h->p))) return rc;
     if ((rc = dmalloc(&h->sched_cnt[0], (size_t)SCHED_BUCKETS))) return rc;
     if ((rc = dmalloc(&h->sched_cnt[1], (size_t)SCHED_BUCKETS))) return rc;
@@ -803,10 +803,11 @@ int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipSt
             nb -= nb % npart;
             const int nitems = a.list ? 4 * blocks : a.p;           // (a list launch: its bound; the kernel stops at *list_count)
             const int cap = cdiv(nitems, npart);
-            const int which = st == h->lng ? 1 : 0;                 // the two launch sites may run at the same time: a set of counters each
-            unsigned *tk = h->pc4_ticket + (size_t)which * PC4_PARTS * 32;
+            // the two launch sites may run at the same time: a set of counters each; a launch with ONE counter (few blocks) has
+            // a counter of its own behind the sixteen, so that the counters of a set always stand at the same value
+            const int which = (st == h->lng ? 2 : 0) + (npart == 1 ? 1 : 0);
+            unsigned *tk = h->pc4_ticket + ((size_t)(which >> 1) * (PC4_PARTS + 1) + (npart == 1 ? PC4_PARTS : 0)) * 32;
             const unsigned tbase = h->pc4_base[which];
-            h->pc4_base[which] += (unsigned)cap + 4u * (unsigned)(nb / npart);   // what this launch takes from each counter in use: its items and one ticket per wave
 #define PC4(NBV, MS)                                                                                                         \
     {                                                                                                                        \
         if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, true>), dim3(nb), dim3(256), lds, st, a, nitems, tk, tbase, npart, cap); \
@@ -818,6 +819,8 @@ int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipSt
             else PC4(2, 8)
 #undef PC4
             KCHECK();
+            // what the launch takes from each counter in use: its items and one ticket per wave (only once it is known to be enqueued)
+            h->pc4_base[which] += (unsigned)cap + 4u * (unsigned)(nb / npart);
             return INSIDER_OK;
         }
     }

@@ -12,7 +12,7 @@ for i, e in enumerate(ev):
     if e[2].startswith("k_cd_cols_reg"):
         seen_cd = True
     elif seen_cd and (e[2].startswith("k_wgemm<") or e[2].startswith("k_wsyrk<") or
-                      (e[2].startswith("k_mm_rows<") and ", true>" in e[2]) or e[2].startswith("k_mm_reduce<")):
+                      (e[2].startswith("k_mm_rows") and ", true>" in e[2]) or e[2].startswith("k_mm_reduce")):
         # the row phase's first kernel: a level Gram GEMM, C'C or V = C A', whichever stream wins
         starts.append(i)
         seen_cd = False

@@ -62,7 +62,7 @@ def main():
     cd_launch = []
     for k in cdk:
         cd_launch += [1024.0 * (2.0 * f + w) for f, w in zip(fs[k], ws.get(k, [0.0] * len(fs[k])))]
-    ent = {"col_stats_bytes_per_launch": stats + total(lambda k: k.startswith("k_mm_rows<") and "false" in k) / 2,
+    ent = {"col_stats_bytes_per_launch": stats + total(lambda k: k.startswith("k_mm_rows") and "false" in k) / 2,
            "cd_bytes_per_launch": cd_launch[-1] if cd_launch else 0.0,
            "cd_bytes_largest_pass": max(cd_launch) if cd_launch else 0.0,
            "cd_bytes_mean_over_launches": sum(cd_launch) / len(cd_launch) if cd_launch else 0.0,
