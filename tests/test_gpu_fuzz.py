@@ -77,10 +77,13 @@ def test_fuzz_outlier_is_not_a_kernels(idx):
             flipped = it
             break
     assert flipped is not None or (max(dev_cov[0], dev_cov[1]) < 1e-7 and dev_cov[2] < 1e-8), (dev_cov, dev)
-    # (iii) the oracle's two forms differ from each other, with no GPU involved, by as much as the library from the parity oracle
+    # (iii) what explains the deviation: the oracle's two forms differ from each other, with no GPU involved, by as much as the
+    #       library from the parity oracle — or (cases of round 5: both oracle forms agree to 1e-14) a gene's stopping decision
+    #       fell on the other side of the tolerance than the oracle's (found above), which moves the result by about the
+    #       tolerance itself
     form_gap = fz.errors(dict(row_matrices={f"factor{i}": a for i, a in enumerate(cov["row_matrices"])},
                               column_factor=cov["column_factor"], traj=cov["traj"]), ref)
-    assert max(form_gap[0], form_gap[1]) > 0.2 * max(dev[0], dev[1]), (form_gap, dev)
+    assert flipped is not None or max(form_gap[0], form_gap[1]) > 0.2 * max(dev[0], dev[1]), (form_gap, dev, flipped)
     # (iv) the deviation stays within what the fixture records (x 3: not bit-stable across compilers of the oracle)
     tol = case["tolerated"]
     assert dev[0] <= 3 * tol["row"] and dev[1] <= 3 * tol["col"] and dev[2] <= 3 * tol["traj"], (dev, tol)
