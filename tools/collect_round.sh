@@ -15,6 +15,15 @@ cp $S/c3_pmc_issue.csv $D/c3_pmc_issue.csv
 cp $S/c3_K40_pmc_issue.csv $D/c3_K40_pmc_issue.csv 2>/dev/null
 cp $S/c5_pmc_issue.csv $D/c5_pmc_issue.csv 2>/dev/null
 cp $S/issue.json $R/profiles/issue.json
+# (gpurun MERGES a call's outputs into gpurun_out/: a second profile job of the round leaves the first one's counter files beside
+# its own, and the traffic figures would be sums over both runs — keep the newest file of each pass only)
+for d in $S/pmc_fetch $S/pmc_write; do
+  for sub in $d/*/; do
+    for kind in counter_collection agent_info; do
+      ls -t $sub*_$kind.csv 2>/dev/null | tail -n +2 | while read f; do rm -f "$f"; done
+    done
+  done
+done
 python3 $R/tools/pmc_csv.py $S/pmc_fetch $S/pmc_write > $D/c3_pmc_summary.csv
 cd $R && INSIDER_COMMIT=${INSIDER_COMMIT:-$(git rev-parse --short HEAD)} python3 tools/pmc_traffic.py c3 $S/pmc_fetch $S/pmc_write $(git rev-parse --short HEAD)
 python3 - <<PY
