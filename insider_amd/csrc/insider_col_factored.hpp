@@ -618,13 +618,15 @@ __device__ __forceinline__ double row_ror4(double v)
 // exactly the natural A layout of X = U' Tab, whose rotations by 4 x lanes (DPP, 36 moves per gene) give the off-diagonal tiles.
 // acc: m1d[bi][x] (diagonal blocks, x < 3), m1o[x] (block (1, 0)), xa[bi][bj][x] (X, all tiles; X + X' in the epilogue).
 // S's diagonal tiles are taken from their lower halves (n a_i a_j and n a_j a_i round differently): Gc is exactly symmetric.
-template <int NB, int WPB, int MAXS>
-__global__ void __launch_bounds__(WPB * 64) k_col_paircnt4s(ColFacArgs a, int nitems, unsigned *__restrict__ ticket, unsigned ticket_base,
+// NS: the k-steps of the table (ceil(rows / 4)) when <= 4 — everything about them is unrolled — or 8: up to eight, tested at run time
+template <int NB, int WPB, int NS>
+__global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(3))) k_col_paircnt4s(ColFacArgs a, int nitems, unsigned *__restrict__ ticket, unsigned ticket_base,
                                                             int npart, int cap, int cs8 /* count bytes per gene, rounded up to 8 */)
 {
     static_assert(NB <= 2, "accumulators of the 4x4x4 form");
     constexpr int KP = Geo<NB>::KP;
-    constexpr int bpl = MAXS <= 4 ? 4 : 8;   // count bytes per lane and block of 16 levels
+    constexpr int bpl = NS <= 4 ? 4 : 8;
+    constexpr int MAXS = NS;   // count bytes per lane and block of 16 levels
     extern __shared__ double s_c4[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *tr = s_c4 + (size_t)w * 16 * 17;
@@ -711,14 +713,22 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4s(ColFacArgs a, int ni
         const double *rp[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) rp[x] = rl[x] + (size_t)pb4 * NB * 64;
-        auto rows_of = [&](int s, double (&av)[4][NB]) {
+        const uint8_t *cqp = clt;   // this lane's count bytes of the current block of 16 levels
+        // the operands of quad s of the current block (s = 4: the next block's first): the factor rows in their four rotations and
+        // the count bytes of the k-steps, requested one quad ahead
+        auto rows_of = [&](int s, double (&av)[4][NB], uint32_t (&cn)[bpl / 4]) {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int bi = 0; bi < NB; ++bi) av[x][bi] = rp[x][(s * NB + bi) * 64];
+            if (cross) {   // wave-uniform
+#pragma unroll
+                for (int d = 0; d < bpl / 4; ++d)   // the lane's bpl count bytes of the quad as dwords (split into bytes at their use:
+                    cn[d] = *reinterpret_cast<const uint32_t *>(cqp + (s < 4 ? 4 * s * bpl : 64 * bpl) + 4 * d);   // nothing here waits)
+            }
         };
         // one quad of levels: S's lower tiles, and U += N' A
-        auto step = [&](const double (&av)[4][NB], double hn, const uint8_t *cq) {
+        auto step = [&](const double (&av)[4][NB], double hn, const uint32_t (&cn)[bpl / 4]) {
             double pr[NB];
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) pr[bb] = hn * av[0][bb];
@@ -733,40 +743,41 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4s(ColFacArgs a, int ni
             if (cross) {
 #pragma unroll
                 for (int T = 0; T < MAXS; ++T)
-                    if (T < a.nsteps) {   // wave-uniform
-                        const double cv = (double)(uint32_t)cq[T];
+                    if (NS <= 4 || T < a.nsteps) {   // wave-uniform
+                        const double cv = (double)((cn[T >> 2] >> (8 * (T & 3))) & 0xffu);
 #pragma unroll
                         for (int bi = 0; bi < NB; ++bi) U[T][bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv, av[0][bi], U[T][bi], 0, 0, 0);
                     }
             }
         };
         double avA[4][NB], avB[4][NB];
+        uint32_t cnA[bpl / 4], cnB[bpl / 4];
         auto compute = [&](int l0, const float4 &hn) {
-            const uint8_t *cq = clt + (size_t)(l0 >> 4) * 64 * bpl;
-            rows_of(1, avB);
+            rows_of(1, avB, cnB);
             __builtin_amdgcn_sched_barrier(0);
-            step(avA, (double)hn.x, cq);
+            step(avA, (double)hn.x, cnA);
             if (l0 + 4 < Lo) {   // wave-uniform
-                rows_of(2, avA);
+                rows_of(2, avA, cnA);
                 __builtin_amdgcn_sched_barrier(0);
-                step(avB, (double)hn.y, cq + 4 * bpl);
+                step(avB, (double)hn.y, cnB);
                 if (l0 + 8 < Lo) {
-                    rows_of(3, avB);
+                    rows_of(3, avB, cnB);
                     __builtin_amdgcn_sched_barrier(0);
-                    step(avA, (double)hn.z, cq + 8 * bpl);
+                    step(avA, (double)hn.z, cnA);
                     if (l0 + 12 < Lo) {
-                        rows_of(4, avA);
+                        rows_of(4, avA, cnA);
                         __builtin_amdgcn_sched_barrier(0);
-                        step(avB, (double)hn.w, cq + 12 * bpl);
+                        step(avB, (double)hn.w, cnB);
                     }
                 }
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x) rp[x] += 4 * NB * 64;
+            cqp += 64 * bpl;
         };
         float4 h0, h1;
         h0 = *reinterpret_cast<const float4 *>(ht + off_h);
-        rows_of(0, avA);
+        rows_of(0, avA, cnA);
         for (int l0 = 0; l0 < Lo; l0 += 32) {
             if (l0 + 16 < Lo) h1 = *reinterpret_cast<const float4 *>(ht + l0 + 16 + off_h);
             compute(l0, h0);
@@ -787,7 +798,7 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4s(ColFacArgs a, int ni
             for (int x = 0; x < 4; ++x) xa[bi][bj][x] = 0.0;
 #pragma unroll
     for (int T = 0; T < MAXS; ++T)
-        if (T < a.nsteps) {   // wave-uniform
+        if (NS <= 4 || T < a.nsteps) {   // wave-uniform
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
                 const double u0 = U[T][bi];
