@@ -593,280 +593,6 @@ __global__ void __launch_bounds__(WPB * 64) k_col_paircnt4(ColFacArgs a, int nit
     }
 }
 
-// lane i of every row of 16 <- lane (i + 16 - N) mod 16 of v (DPP row_ror:N on both halves)
-template <int N>
-__device__ __forceinline__ double row_ror4(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// k_col_paircnt4 with the cross terms moved to the table side (round 5; categorical covariates only).
-//   Gc = M + M',  M = sum_l a_l p_l',  p_l = 1/2 n_l a_l + sum_q n(l, q) tab_q
-//      = S + X + X',   S = sum_l n_l a_l a_l'  (symmetric),   X = sum_q u_q tab_q',   u_q = sum_l n(l, q) a_l.
-// S is symmetric: on the 4 x 4 tiling of a 32 x 32 block only the lower tiles are needed — 3 + 4 + 3 = 10 of the Latin square's
-// 16 instructions per four levels (a diagonal 16 x 16 block needs the rotations x = 0, 1, 2: the tile (0, 3) that x = 1 yields
-// is (3, 0) transposed).  The cross terms become rank-one updates over the TABLE rows (12 at c3) instead of over the levels
-// (110): U = N' A costs what the count product cost (ceil(rows / 4) x NB instructions per four levels, on the 4x4x4 form: the
-// count operand with the levels along k is read from an LDS copy of the gene's count bytes, one ds_read_u8 + one conversion
-// each), and X = U' Tab is ceil(rows / 4) x 16 instructions per GENE.  c3: 280 + 150 + 48 = 478 instructions of 16 cycles per
-// gene against 448 + 42 of the 16x16x4 form (= 4200 cycles) for k_col_paircnt4.
-// Operand maps (lane = (g4, c16 = 4 b + i)):  U += N' A:  A = count of (level 4 Qd + g4, table row 4 T + (c16 & 3)) — the same
-// for the four blocks —, B = the factor rows in the natural layout, D = U[T][bi] of lane (g4 = row % 4 of the table, c16 = component):
-// exactly the natural A layout of X = U' Tab, whose rotations by 4 x lanes (DPP, 36 moves per gene) give the off-diagonal tiles.
-// acc: m1d[bi][x] (diagonal blocks, x < 3), m1o[x] (block (1, 0)), xa[bi][bj][x] (X, all tiles; X + X' in the epilogue).
-// S's diagonal tiles are taken from their lower halves (n a_i a_j and n a_j a_i round differently): Gc is exactly symmetric.
-// NS: the k-steps of the table (ceil(rows / 4)) when <= 4 — everything about them is unrolled — or 8: up to eight, tested at run time
-template <int NB, int WPB, int NS>
-__global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(3))) k_col_paircnt4s(ColFacArgs a, int nitems, unsigned *__restrict__ ticket, unsigned ticket_base,
-                                                            int npart, int cap, int cs8 /* count bytes per gene, rounded up to 8 */)
-{
-    static_assert(NB <= 2, "accumulators of the 4x4x4 form");
-    constexpr int KP = Geo<NB>::KP;
-    constexpr int bpl = NS <= 4 ? 4 : 8;
-    constexpr int MAXS = NS;   // count bytes per lane and block of 16 levels
-    extern __shared__ double s_c4[];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    double *tr = s_c4 + (size_t)w * 16 * 17;
-    uint8_t *cbw = reinterpret_cast<uint8_t *>(s_c4 + (size_t)WPB * 16 * 17) + (size_t)w * cs8;
-    double *tabs = s_c4 + (size_t)WPB * 16 * 17 + (size_t)WPB * cs8 / 8;
-    double *rows = tabs + 4 * a.nsteps * KP;
-    const int npos = a.c;
-    for (int i = threadIdx.x; i < 4 * a.nsteps * KP; i += WPB * 64) {
-        const int r = i / KP, k = i % KP;
-        const int q = r < a.tab_skip_lo ? r : r + a.tab_skip_n;
-        tabs[i] = r < a.tab_rows ? a.Astack[(size_t)q * KP + k] : 0.0;
-    }
-    {
-        int pb4 = 0;
-        for (int t = 0; t < npos; ++t) {
-            const int nq = (a.L[t] + 3) >> 2;
-            const double *At = a.Astack + (size_t)a.off[t] * KP;
-            for (int i = threadIdx.x; i < 4 * nq * KP; i += WPB * 64) {
-                const int l = i / KP, k = i % KP;
-                rows[((size_t)(pb4 + (l >> 2)) * NB + (k >> 4)) * 64 + (l & 3) * 16 + (k & 15)] = At[i];
-            }
-            pb4 += nq;
-        }
-        for (int i = threadIdx.x; i < 4 * KP; i += WPB * 64) rows[(size_t)pb4 * NB * 64 + i] = 0.0;
-    }
-    __syncthreads();
-    const int g4 = lane >> 4, c16 = lane & 15;
-    double tb[MAXS][NB];
-#pragma unroll
-    for (int s = 0; s < MAXS; ++s)
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) tb[s][bb] = s < a.nsteps ? tabs[(4 * s + g4) * KP + 16 * bb + c16] : 0.0;
-    const unsigned off_h = (unsigned)g4 * 4u;
-    const double *rl[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) rl[x] = rows + g4 * 16 + ((c16 + 4 * x) & 15);
-    // this lane's count bytes in the LDS copy: level g4 of a quad, table row (c16 & 3) of a k-step
-    const uint8_t *cl = cbw + ((c16 & 3) * 16 + g4) * bpl;
-    const int part = blockIdx.x % npart;
-    unsigned *tk = ticket + 32 * part;
-    auto take = [&]() {
-        unsigned v = 0;
-        if (lane == 0) v = atomicAdd(tk, 1u);
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)v) - ticket_base;
-    };
-    for (unsigned cur = take(), nxt; cur < (unsigned)cap; cur = nxt) {
-    nxt = take();
-    if ((int)cur * npart + part >= nitems) continue;
-    int j = (int)cur * npart + part;   // wave-uniform
-    if (a.list) {
-        if (j >= *a.list_count) continue;
-        j = a.list[j];
-    } else {
-        if (a.skip_bkt && (int)a.skip_bkt[j] <= *a.skip_last) continue;
-    }
-    double qh[NB];
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) qh[bb] = a.Qheld[(size_t)j * KP + 16 * bb + c16];
-    const double ss = a.yy_all[j] - a.yy_train[j];
-    {   // the gene's count bytes -> LDS (the previous gene's epilogue is behind a wave_sync)
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.cnt + (size_t)j * a.cnt_stride);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(cbw);
-        for (int i = lane; i < a.cnt_stride / 4; i += WAVE) dst[i] = src[i];
-    }
-    double m1d[NB][3], m1o[4], U[MAXS][NB];
-#pragma unroll
-    for (int bi = 0; bi < NB; ++bi)
-#pragma unroll
-        for (int x = 0; x < 3; ++x) m1d[bi][x] = 0.0;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) m1o[x] = 0.0;
-#pragma unroll
-    for (int s = 0; s < MAXS; ++s)
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) U[s][bb] = 0.0;
-    const float *hj = a.hn + (size_t)j * a.hn_stride;
-    wave_sync();
-    int pb4 = 0;
-    for (int t = 0; t < npos; ++t) {
-        const int Lo = a.L[t];
-        const bool cross = a.nlater[t] > 0;   // wave-uniform
-        const float *ht = hj + a.hn_off[t];
-        const uint8_t *clt = cl + a.cnt_off[t];
-        const double *rp[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) rp[x] = rl[x] + (size_t)pb4 * NB * 64;
-        const uint8_t *cqp = clt;   // this lane's count bytes of the current block of 16 levels
-        // the operands of quad s of the current block (s = 4: the next block's first): the factor rows in their four rotations and
-        // the count bytes of the k-steps, requested one quad ahead
-        auto rows_of = [&](int s, double (&av)[4][NB], uint32_t (&cn)[bpl / 4]) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int bi = 0; bi < NB; ++bi) av[x][bi] = rp[x][(s * NB + bi) * 64];
-            if (cross) {   // wave-uniform
-#pragma unroll
-                for (int d = 0; d < bpl / 4; ++d)   // the lane's bpl count bytes of the quad as dwords (split into bytes at their use:
-                    cn[d] = *reinterpret_cast<const uint32_t *>(cqp + (s < 4 ? 4 * s * bpl : 64 * bpl) + 4 * d);   // nothing here waits)
-            }
-        };
-        // one quad of levels: S's lower tiles, and U += N' A
-        auto step = [&](const double (&av)[4][NB], double hn, const uint32_t (&cn)[bpl / 4]) {
-            double pr[NB];
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb) pr[bb] = hn * av[0][bb];
-#pragma unroll
-            for (int bi = 0; bi < NB; ++bi)
-#pragma unroll
-                for (int x = 0; x < 3; ++x) m1d[bi][x] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[x][bi], pr[bi], m1d[bi][x], 0, 0, 0);
-            if constexpr (NB == 2) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) m1o[x] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[x][1], pr[0], m1o[x], 0, 0, 0);
-            }
-            if (cross) {
-#pragma unroll
-                for (int T = 0; T < MAXS; ++T)
-                    if (NS <= 4 || T < a.nsteps) {   // wave-uniform
-                        const double cv = (double)((cn[T >> 2] >> (8 * (T & 3))) & 0xffu);
-#pragma unroll
-                        for (int bi = 0; bi < NB; ++bi) U[T][bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(cv, av[0][bi], U[T][bi], 0, 0, 0);
-                    }
-            }
-        };
-        double avA[4][NB], avB[4][NB];
-        uint32_t cnA[bpl / 4], cnB[bpl / 4];
-        auto compute = [&](int l0, const float4 &hn) {
-            rows_of(1, avB, cnB);
-            __builtin_amdgcn_sched_barrier(0);
-            step(avA, (double)hn.x, cnA);
-            if (l0 + 4 < Lo) {   // wave-uniform
-                rows_of(2, avA, cnA);
-                __builtin_amdgcn_sched_barrier(0);
-                step(avB, (double)hn.y, cnB);
-                if (l0 + 8 < Lo) {
-                    rows_of(3, avB, cnB);
-                    __builtin_amdgcn_sched_barrier(0);
-                    step(avA, (double)hn.z, cnA);
-                    if (l0 + 12 < Lo) {
-                        rows_of(4, avA, cnA);
-                        __builtin_amdgcn_sched_barrier(0);
-                        step(avB, (double)hn.w, cnB);
-                    }
-                }
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x) rp[x] += 4 * NB * 64;
-            cqp += 64 * bpl;
-        };
-        float4 h0, h1;
-        h0 = *reinterpret_cast<const float4 *>(ht + off_h);
-        rows_of(0, avA, cnA);
-        for (int l0 = 0; l0 < Lo; l0 += 32) {
-            if (l0 + 16 < Lo) h1 = *reinterpret_cast<const float4 *>(ht + l0 + 16 + off_h);
-            compute(l0, h0);
-            if (l0 + 16 < Lo) {
-                if (l0 + 32 < Lo) h0 = *reinterpret_cast<const float4 *>(ht + l0 + 32 + off_h);
-                compute(l0 + 16, h1);
-            }
-        }
-        pb4 += (Lo + 3) >> 2;
-    }
-    // X = U' Tab: ceil(rows / 4) k-steps of the Latin square
-    double xa[NB][NB][4];
-#pragma unroll
-    for (int bi = 0; bi < NB; ++bi)
-#pragma unroll
-        for (int bj = 0; bj < NB; ++bj)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) xa[bi][bj][x] = 0.0;
-#pragma unroll
-    for (int T = 0; T < MAXS; ++T)
-        if (NS <= 4 || T < a.nsteps) {   // wave-uniform
-#pragma unroll
-            for (int bi = 0; bi < NB; ++bi) {
-                const double u0 = U[T][bi];
-                const double ur[4] = {u0, row_ror4<12>(u0), row_ror4<8>(u0), row_ror4<4>(u0)};
-#pragma unroll
-                for (int bj = 0; bj < NB; ++bj)
-#pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        xa[bi][bj][x] = __builtin_amdgcn_mfma_f64_4x4x4f64(ur[x], tb[T][bj], xa[bi][bj][x], 0, 0, 0);
-            }
-        }
-    // epilogue: Gc = 2 M1 (symmetric) + X + X', block by block through the 16 x 17 tile; the record as cf_store writes it
-    {
-        const int b = c16 >> 2, jj = c16 & 3;
-        double *out = a.stat + (size_t)j * Geo<NB>::STAT;
-        int blk = 0;
-#pragma unroll
-        for (int bi = 0; bi < NB; ++bi)
-#pragma unroll
-            for (int bj = 0; bj <= bi; ++bj, ++blk) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) tr[(4 * ((b + x) & 3) + g4) * 17 + 4 * b + jj] = xa[bi][bj][x];
-                wave_sync();
-                d4 res;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) res[r] = tr[(g4 + 4 * r) * 17 + c16];
-                wave_sync();
-#pragma unroll
-                for (int x = 0; x < 4; ++x) tr[(4 * ((b + x) & 3) + g4) * 17 + 4 * b + jj] = xa[bj][bi][x];
-                wave_sync();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) res[r] += tr[c16 * 17 + g4 + 4 * r];
-                wave_sync();
-                if (bi != bj) {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) tr[(4 * ((b + x) & 3) + g4) * 17 + 4 * b + jj] = m1o[x];
-                } else {
-                    // lower tiles and the lower halves of the diagonal tiles, each also mirrored; x = 1's tile (0, 3) is (3, 0)
-                    // transposed; x = 2's tiles (0, 2), (1, 3) repeat (2, 0), (3, 1)
-#pragma unroll
-                    for (int x = 0; x < 3; ++x) {
-                        const int rr = 4 * ((b + x) & 3) + g4, cc = 4 * b + jj;
-                        const bool keep = x == 0 ? g4 >= jj : (x == 1 ? true : b < 2);
-                        if (keep) {
-                            tr[rr * 17 + cc] = m1d[bi][x];
-                            tr[cc * 17 + rr] = m1d[bi][x];
-                        }
-                    }
-                }
-                wave_sync();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ra = 16 * bi + g4 + 4 * r, cb = 16 * bj + c16;
-                    const double g = res[r] + 2.0 * tr[(g4 + 4 * r) * 17 + c16];
-                    res[r] = ((ra < a.K && cb < a.K) ? a.RtR[ra * KP + cb] : 0.0) - g;
-                }
-                wave_sync();
-                if (bi == NB - 1 && g4 == 3) {
-                    const int col = 16 * bj + c16;
-                    res[3] = col < a.K ? qh[bj] : (col == KP - 1 ? ss : 0.0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) out[blk * 256 + (g4 + 4 * r) * 16 + c16] = res[r];
-            }
-    }
-    }
-}
-
 // The real-valued count table of the continuous covariates (ColFacArgs::zt) and the held-out sums sum_{i in H(j)} x_ij z_ik,
 // once per data set.  One wave per gene; every sum runs over the gene's held-out list in list order (fixed order:
 // reproducible), each lane owning the levels l = lane, lane + 64, ... of a position.  lev: [c][n] zero-based levels; Zc: [m][n].

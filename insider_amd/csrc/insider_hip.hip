@@ -813,25 +813,10 @@ int launch_paircnt(insider_hip_handle *h, const ColFacArgs &a, int blocks, hipSt
         if (a.zt) hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, true>), dim3(nb), dim3(256), lds, st, a, nitems, tk, tbase, npart, cap); \
         else hipLaunchKernelGGL((k_col_paircnt4<NBV, 4, MS, false>), dim3(nb), dim3(256), lds, st, a, nitems, tk, tbase, npart, cap); \
     }
-            // col_mfma4 = 2: the cross terms on the table side, S's lower tiles only (k_col_paircnt4s; categorical covariates)
-            const int cs8 = (int)round_up(a.cnt_stride, 8);
-            const size_t lds_s = lds - (size_t)h->KP * h->KP * sizeof(double) + (size_t)4 * cs8;   // no R'R copy, the waves' count bytes
-#define PC4S(NBV, MS) hipLaunchKernelGGL((k_col_paircnt4s<NBV, 4, MS>), dim3(nb), dim3(256), lds_s, st, a, nitems, tk, tbase, npart, cap, cs8)
-            if (h->col_mfma4 >= 2 && !a.zt && lds_s <= 64 * 1024) {
-                if (h->NB == 1) { if (a.nsteps <= 4) PC4S(1, 4); else PC4S(1, 8); }   // (NS = 4 with fewer k-steps: zero table rows, zero counts)
-                else switch (a.nsteps) {
-                    case 1: PC4S(2, 1); break;
-                    case 2: PC4S(2, 2); break;
-                    case 3: PC4S(2, 3); break;
-                    case 4: PC4S(2, 4); break;
-                    default: PC4S(2, 8); break;
-                }
-            } else
             if (h->NB == 1 && a.nsteps <= 4) PC4(1, 4)
             else if (h->NB == 1) PC4(1, 8)
             else if (a.nsteps <= 4) PC4(2, 4)
             else PC4(2, 8)
-#undef PC4S
 #undef PC4
             KCHECK();
             // what the launch takes from each counter in use: its items and one ticket per wave (only once it is known to be enqueued)

@@ -866,7 +866,7 @@ def test_pair_count_statistics_on_the_4x4x4_matrix_instruction(oracle, kw, m):
     Z = np.asfortranarray(rng.standard_normal((w.n, m))) if m else None
     U0 = [np.asfortranarray(rng.normal(0.0, 0.001, size=(m, w.K)))] if m else []
     out = {}
-    for fine in (2, 1, 0):
+    for fine in (1, 0):
         ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
         for k, v in PATHS["pair"].items():
             ds.set_option(k, v)
@@ -878,12 +878,11 @@ def test_pair_count_statistics_on_the_4x4x4_matrix_instruction(oracle, kw, m):
         ds.close()
     ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + U0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
                           max_iter=10, seed=4, **(dict(ctns=Z) if m else {}))
-    for fine in (2, 1, 0):
+    for fine in (1, 0):
         np.testing.assert_allclose(out[fine]["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-8, equal_nan=True)
         assert relerr(out[fine]["column_factor"], ref["column_factor"]) < 1e-6
-    for fine in (2, 1):
-        np.testing.assert_allclose(out[fine]["traj"][:, 1:8], out[0]["traj"][:, 1:8], rtol=1e-11, equal_nan=True)
-        assert relerr(out[fine]["column_factor"], out[0]["column_factor"]) < 1e-9
+    np.testing.assert_allclose(out[1]["traj"][:, 1:8], out[0]["traj"][:, 1:8], rtol=1e-11, equal_nan=True)
+    assert relerr(out[1]["column_factor"], out[0]["column_factor"]) < 1e-9
 
 
 @pytest.mark.parametrize("alpha,tuning", [(0.4, 1), (0.0, 1), (0.3, 0), (0.0, 0), (1.0, 1)])
