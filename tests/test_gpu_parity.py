@@ -327,6 +327,45 @@ def test_optimize_31_iterations(oracle, case, paths):
         assert np.isnan(got["test_rmse"])
 
 
+@pytest.mark.parametrize("kw,m", [(dict(n=48, p=16500, level_counts=(18, 3), K=5, f=0.2), 0),
+                                  (dict(n=60, p=16400, level_counts=(50, 4, 3), K=17, f=0.15, with_na=True), 0),
+                                  (dict(n=48, p=16390, level_counts=(12, 5), K=6, f=0.2), 2)],
+                         ids=["two-cov", "three-cov-K17-gemm", "ctns2"])
+def test_streaming_products_and_ticketed_statistics_at_many_genes(oracle, kw, m):
+    """From 16384 genes on the row phase's products run on k_mm_rows2 / k_mm_reduce2 (option mm_fast) and the pair-count
+    statistics' resident blocks (768 at most) each take many genes by ticket — the suite's other oracle comparisons have a few
+    hundred genes and never reach either.  Few samples keep the oracle to seconds.  Against the oracle, against round 4's
+    kernels (mm_fast = 0, col_mfma4 = 0), and with the two experimental arrangements of round 5 (join_lean, q_split), which
+    may only reorder sums."""
+    w = workloads.small(seed=77, **kw)
+    rng = np.random.default_rng(6)
+    Z = np.asfortranarray(rng.standard_normal((w.n, m))) if m else None
+    U0 = [np.asfortranarray(rng.normal(0.0, 0.001, size=(m, w.K)))] if m else []
+    out = {}
+    for name, opts in (("default", {}), ("round4", dict(mm_fast=0, col_mfma4=0)), ("joins", dict(join_lean=7)), ("qsplit", dict(q_split=1))):
+        ds = api.InsiderData(w.X, w.levels, w.M_train, w.M_test, ctns_confounder=Z)
+        for k, v in PATHS["pair"].items():
+            ds.set_option(k, v)
+        for k, v in opts.items():
+            ds.set_option(k, v)
+        A, C = _cp(w)
+        out[name] = ds.optimize(A + [u.copy(order="F") for u in U0], C, w.K, w.lam, w.lam, w.alpha, tuning=1, max_iter=4, seed=4,
+                                inc_continuous=1 if m else 0)
+        assert ds.profile()["col_pair"] and ds.profile()["row_merged"]
+        ds.close()
+    ref = oracle.optimize(w.X, w.levels, w.n_levels, w.A0 + U0, w.C0, w.M_train, w.M_test, w.lam, w.lam, w.alpha, tuning=1,
+                          max_iter=4, seed=4, **(dict(ctns=Z) if m else {}))
+    for name, got in out.items():
+        np.testing.assert_allclose(got["traj"][:, 1:8], ref["traj"][:, 1:8], rtol=1e-8, equal_nan=True, err_msg=name)
+        assert relerr(got["column_factor"], ref["column_factor"]) < 1e-6, name
+        for i, a in enumerate(ref["row_matrices"]):
+            assert relerr(got["row_matrices"][f"factor{i}"], a) < 1e-6, (name, i)
+    for name in ("round4", "joins", "qsplit"):
+        np.testing.assert_allclose(out[name]["traj"][:, 1:8], out["default"]["traj"][:, 1:8], rtol=1e-10, equal_nan=True, err_msg=name)
+        assert relerr(out[name]["column_factor"], out["default"]["column_factor"]) < 1e-8, name
+    assert np.array_equal(out["joins"]["column_factor"], out["default"]["column_factor"])   # the joins change no arithmetic
+
+
 @pytest.mark.parametrize("opts", [dict(cd_variant=1), dict(cd_variant=2), dict(order_mode=1), dict(max_sweeps=7),
                                   dict(cd_variant=1, max_sweeps=5, order_mode=1),
                                   dict(cd_variant=2, max_sweeps=6, order_mode=1), dict(row_merged=0), dict(row_merged=2), dict(col_factored=0), dict(col_factored=2), dict(col_factored=3),
